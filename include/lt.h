@@ -1,0 +1,219 @@
+/*
+ * lt.h -- C ABI of the MI355X photon-transport hot path (liblt_hip.so).
+ *
+ * The reference (zhouyifan233/light-transport) has no FFI: its only boundary is
+ * the Python call  render_scene(scene, primitives, bvh) -> ndarray
+ * (LightTransportSimulator/light_transport/src/path_tracing_fix1.py:139-169),
+ * fed by constructor objects (primitives.py:99, material.py:28, scene.py:53,
+ * bvh_new.py:11,60,148,282).  This header is the boundary a maintainer binds
+ * with ctypes from the (empty) reference slot src/photon_tracing.py; see
+ * INTEGRATION.md for the binding stub.  Each entry point names the reference
+ * construct whose role it takes over.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative LT_E_* code on failure;
+ *     lt_last_error(ctx) returns a message for the last failure on that ctx
+ *     (ctx == NULL: the last failure of lt_create on this thread).
+ *   - all host pointers stay owned by the caller; set_* functions copy.
+ *   - one ctx = one GPU + one HIP stream.  A ctx is not thread-safe; distinct
+ *     ctxs are independent.
+ *   - there is NO CPU fallback: lt_create fails when no gfx950-class device /
+ *     code object is usable.
+ */
+#ifndef LT_H_
+#define LT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_ABI_VERSION 1
+
+/* error codes */
+#define LT_OK 0
+#define LT_E_INVALID (-1)  /* bad argument / inconsistent scene            */
+#define LT_E_STATE (-2)    /* call order: e.g. launch before set_grid      */
+#define LT_E_HIP (-3)      /* HIP runtime error (message has the detail)   */
+#define LT_E_NOMEM (-4)
+#define LT_E_UNSUPPORTED (-5)
+
+/* tally storage of the voxel grid (lt_set_grid) */
+#define LT_TALLY_F32 0   /* global_atomic_add_f32                         */
+#define LT_TALLY_F64 1   /* global_atomic_add_f64                         */
+#define LT_TALLY_U64FX 2 /* u64 fixed point, 2^40 units per unit weight:
+                            order-independent, bit-reproducible           */
+#define LT_FX_SCALE 1099511627776.0 /* 2^40 */
+
+/* photon sources (lt_set_source) */
+#define LT_SRC_PENCIL 0      /* pos, dir                                   */
+#define LT_SRC_COSINE_QUAD 1 /* quad corner=pos, normal=dir,
+                                extra[0..2]=edge1, extra[3..5]=edge2;
+                                cosine-weighted about dir (reference
+                                utils.py:132-161, light_samples.py:64-116) */
+
+/* lt_launch flags */
+#define LT_FLAG_F32_WALK 1u /* walk arithmetic in f32 (default: f64, the
+                               reference's dtype, e.g. scene.py:31-50)     */
+
+/* optical medium -- takes the role of Material.ior (material.py:22) plus the
+ * volumetric coefficients the reference lacks. */
+typedef struct lt_medium {
+    double mu_a; /* absorption coefficient  [1/length] */
+    double mu_s; /* scattering coefficient  [1/length] */
+    double g;    /* Henyey-Greenstein anisotropy (medium_samples.py:14-16) */
+    double n;    /* refractive index */
+} lt_medium;
+
+/* flattened BVH node, DFS pre-order -- role of LinearBVHNode
+ * (bvh_new.py:60-67) with second_child_offset = FIRST index of the right
+ * subtree (the reference's own "#TODO: fix this", bvh_new.py:295). */
+typedef struct lt_bvh_node {
+    double lo[3];
+    double hi[3];
+    int32_t offset;  /* leaf: primitives_offset; interior: second child   */
+    int32_t n_prims; /* >0: leaf                                           */
+    int32_t axis;    /* interior: split axis 0..2                          */
+    int32_t pad_;
+} lt_bvh_node;
+
+/* energy bookkeeping.  Invariant:
+ *   photons = w_absorbed + w_lost_outside_grid + w_escaped_top
+ *           + w_escaped_bottom + w_escaped_mesh + w_specular
+ *           + w_roulette_net + w_capped                                  */
+typedef struct lt_counters {
+    uint64_t photons;
+    uint64_t steps; /* photon-steps: iterations of the hop/drop/spin loop */
+    double w_absorbed;
+    double w_lost_outside_grid;
+    double w_escaped_top;
+    double w_escaped_bottom;
+    double w_escaped_mesh;
+    double w_specular;
+    double w_roulette_net;
+    double w_capped;
+} lt_counters;
+
+typedef struct lt_ctx lt_ctx;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int lt_abi_version(void);
+/* role of: constructing a Scene (scene.py:53-73) bound to one device */
+int lt_create(lt_ctx** out, int device_id);
+int lt_destroy(lt_ctx* ctx);
+const char* lt_last_error(const lt_ctx* ctx);
+
+/* ---- scene ------------------------------------------------------------- */
+/* media table; index = medium id used by layers / triangles */
+int lt_set_media(lt_ctx* ctx, const lt_medium* media, int n);
+/* layered slab: n layers, z_bounds[n+1] ascending (last may be +inf),
+ * ambient indices above z_bounds[0] / below z_bounds[n].  Clears any mesh. */
+int lt_set_layers(lt_ctx* ctx, const double* z_bounds, const int32_t* medium_idx,
+                  int n, double n_above, double n_below);
+/* triangle mesh + flattened BVH.  verts [T][3][3] (role of
+ * PreComputedTriangle.vertex_1..3, primitives.py:99-111, in BVH order =
+ * ordered_prims of build_bvh, bvh_new.py:148).  med_front/med_back: medium id
+ * on the +normal / -normal side, -1 = exterior (photon leaves the scene).
+ * Clears any layers. */
+int lt_set_mesh(lt_ctx* ctx, const double* verts, const int32_t* med_front,
+                const int32_t* med_back, int n_tris, const lt_bvh_node* nodes,
+                int n_nodes);
+/* voxel grid (tally) -- role of Scene.image (scene.py:66).  C-order
+ * [nz][ny][nx]; allocates and zeroes the device grid and the counters. */
+int lt_set_grid(lt_ctx* ctx, int nx, int ny, int nz, const double origin[3],
+                const double voxel[3], int tally_dtype);
+/* source -- role of sample_light (light_samples.py:90-116).  start_medium:
+ * medium id the photon starts in (mesh scenes; ignored for layers). */
+int lt_set_source(lt_ctx* ctx, int type, const double pos[3], const double dir[3],
+                  const double* extra, int start_medium);
+int lt_set_max_steps(lt_ctx* ctx, uint32_t max_steps);
+/* launch geometry: resident workgroups per CU and threads per workgroup
+ * (multiples of 64).  0 keeps the default. */
+int lt_set_launch_config(lt_ctx* ctx, int blocks_per_cu, int threads_per_block);
+
+/* ---- run --------------------------------------------------------------- */
+/* role of render_scene (path_tracing_fix1.py:139-169): trace photons
+ * [photon_offset, photon_offset + n_photons) asynchronously on the ctx stream,
+ * ACCUMULATING into the grid and counters.
+ *   rng_table == NULL : rocRAND XORWOW, state re-seeded per photon from
+ *                       (seed, photon id) -- results do not depend on launch
+ *                       geometry or on which rank traces which id range.
+ *   rng_table != NULL : "table RNG" of the reference (scene.py:68-69,
+ *                       path_tracing_fix1.py:28-29): host array
+ *                       [n_photons][table_steps][4] of uniforms in [0,1),
+ *                       addressed by (photon - photon_offset, step). */
+int lt_launch(lt_ctx* ctx, uint64_t n_photons, uint64_t photon_offset, uint64_t seed,
+              const double* rng_table, uint64_t table_steps, uint32_t flags);
+int lt_sync(lt_ctx* ctx);
+/* milliseconds of device time spent in the transport kernel by the last
+ * lt_launch (HIP events on the ctx stream); valid after lt_sync. */
+int lt_last_kernel_ms(lt_ctx* ctx, double* ms);
+int lt_zero_tally(lt_ctx* ctx); /* zero grid + counters (async)           */
+
+/* ---- readback ---------------------------------------------------------- */
+/* blocking D2H of the raw tally ([nz][ny][nx], dtype as set) */
+int lt_read_grid(lt_ctx* ctx, void* host_out, size_t bytes);
+/* blocking D2H, converted to float64 absorbed weight per voxel */
+int lt_read_grid_f64(lt_ctx* ctx, double* host_out, size_t n_voxels);
+int lt_read_counters(lt_ctx* ctx, lt_counters* out);
+int lt_grid_device_ptr(lt_ctx* ctx, void** ptr, size_t* bytes);
+int lt_counters_device_ptr(lt_ctx* ctx, void** ptr, size_t* bytes);
+void* lt_stream(lt_ctx* ctx); /* hipStream_t of the ctx */
+/* sum-reduce grid + counters over an RCCL communicator (ncclComm_t), on the
+ * ctx stream; root < 0 = all-reduce.  librccl is loaded on first use. */
+int lt_reduce_grid(lt_ctx* ctx, void* nccl_comm, int root);
+
+/* ---- geometry / sampling queries on the device ------------------------- */
+/* These run the SAME __device__ functions the walk uses, one lane per query,
+ * so the reference's per-function behaviour can be checked in isolation. */
+
+/* nearest hit of n rays against the ctx mesh -- role of hit_object /
+ * intersect_bvh (utils.py:53-68, bvh_new.py:414-482), predicate
+ * EPSILON < t < tmax.  prim_out = -1, t_out = +inf when nothing is hit.
+ * use_bvh = 0: brute force over all triangles. */
+int lt_intersect_rays(lt_ctx* ctx, const double* origins, const double* dirs,
+                      const double* tmax, size_t n, int use_bvh, int32_t* prim_out,
+                      double* t_out);
+/* pairwise Moller-Trumbore -- role of triangle_intersect
+ * (intersects.py:46-104).  tris [n][3][3]; t_out = NaN for "None". */
+int lt_triangle_intersect(lt_ctx* ctx, const double* origins, const double* dirs,
+                          const double* tris, size_t n, double* t_out);
+/* pairwise slab test -- role of intersect_bounds (intersects.py:179-196).
+ * boxes [n][2][3] (min,max); hit_out 0/1. */
+int lt_intersect_bounds(lt_ctx* ctx, const double* origins, const double* dirs,
+                        const double* tmax, const double* boxes, size_t n,
+                        int32_t* hit_out);
+/* sampling helpers, n independent evaluations each:
+ *  LT_FN_HG_PDF       in: cos_theta, g            out: [1] henyey_greenstein (medium_samples.py:14-16)
+ *  LT_FN_HG_SAMPLE    in: xi, g                   out: [1] deflection cosine (Appendix C.6)
+ *  LT_FN_ONB          in: n[3]                    out: [6] v2,v3 (utils.py:72-80)
+ *  LT_FN_DISK         in: u[2]                    out: [2] (utils.py:115-128)
+ *  LT_FN_COSINE_HEMI  in: n[3], wi[3], u[2]       out: [4] dir, pdf (utils.py:132-161)
+ *  LT_FN_REFLECT      in: v[3], n[3]              out: [3] (brdf.py:8-9)
+ *  LT_FN_BOUNDARY     in: d[3], n[3], n1, n2      out: [5] R_fresnel, cos_t, refracted[3] (Appendix C.5)
+ *  LT_FN_SPIN         in: u[3], cos_t, phi_xi     out: [3] rotated direction (Appendix C.6)
+ * in/out are row-major [n][k]. */
+#define LT_FN_HG_PDF 0
+#define LT_FN_HG_SAMPLE 1
+#define LT_FN_ONB 2
+#define LT_FN_DISK 3
+#define LT_FN_COSINE_HEMI 4
+#define LT_FN_REFLECT 5
+#define LT_FN_BOUNDARY 6
+#define LT_FN_SPIN 7
+int lt_eval(lt_ctx* ctx, int fn, const double* in, size_t n, double* out);
+/* first `count` raw 32-bit XORWOW outputs of photon `photon_id` under `seed`
+ * (checks the per-photon seeding against the oracle's restatement) */
+int lt_rng_raw(lt_ctx* ctx, uint64_t seed, uint64_t photon_id, uint32_t count,
+               uint32_t* out);
+
+/* device description for bench reports */
+int lt_device_info(lt_ctx* ctx, char* name, size_t name_len, int* n_cus,
+                   int* clock_mhz, size_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LT_H_ */

@@ -1,0 +1,216 @@
+/*
+ * lt_oracle.c -- CPU oracle (TEST INFRASTRUCTURE ONLY; see lt_oracle.h for the
+ * pinning statement: reference functions pinned by golden vectors, the
+ * volumetric walk PARITY UNPINNED vs the reference and pinned analytically).
+ *
+ * Build: make -C oracle   (gcc, -ffp-contract=off so that every operation is a
+ * separately rounded IEEE operation as in the reference's NumPy float64 code).
+ */
+#define _GNU_SOURCE
+#include "lt_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- XORWOW, restating the published generator (Marsaglia 2003, "Xorshift
+ * RNGs", xorwow) with rocRAND 3.x's seeding for (seed, subsequence 0, offset 0)
+ * -- rocRAND is the third-party library the product calls on the device
+ * (/opt/rocm/include/rocrand/rocrand_xorwow.h, ROCm 7.2); tests/ check this
+ * restatement bit-for-bit against the device generator (lt_rng_raw). -------- */
+typedef struct lto_xorwow { uint32_t x[5]; uint32_t d; } lto_xorwow;
+
+static inline uint64_t lto_mix_seed(uint64_t seed, uint64_t photon_id)
+{   /* splitmix64 finaliser over (seed, photon id): one stream per photon */
+    uint64_t z = seed + (photon_id + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+static inline void lto_xorwow_seed(lto_xorwow* s, uint64_t seed)
+{
+    s->x[0] = 123456789U; s->x[1] = 362436069U; s->x[2] = 521288629U;
+    s->x[3] = 88675123U;  s->x[4] = 5783321U;   s->d = 6615241U;
+    const uint32_t s0 = (uint32_t)seed ^ 0x2c7f967fU;
+    const uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xa03697cbU;
+    const uint32_t t0 = 1228688033U * s0;
+    const uint32_t t1 = 2073658381U * s1;
+    s->x[0] += t0; s->x[1] ^= t0; s->x[2] += t1; s->x[3] ^= t1; s->x[4] += t0;
+    s->d += t1 + t0;
+}
+
+static inline uint32_t lto_xorwow_next(lto_xorwow* s)
+{
+    const uint32_t t = s->x[0] ^ (s->x[0] >> 2);
+    s->x[0] = s->x[1]; s->x[1] = s->x[2]; s->x[2] = s->x[3]; s->x[3] = s->x[4];
+    s->x[4] = (s->x[4] ^ (s->x[4] << 4)) ^ (t ^ (t << 1));
+    s->d += 362437U;
+    return s->d + s->x[4];
+}
+
+/* uniforms in (0,1]: rocrand_uniform_double (two draws, 53 bits) and
+ * rocrand_uniform (one draw) -- rocrand_uniform.h:67,102-109 */
+static inline double lto_uniform_f64(lto_xorwow* s)
+{
+    uint32_t v1 = lto_xorwow_next(s), v2 = lto_xorwow_next(s);
+    uint64_t v = ((uint64_t)(v2 >> 11) << 32) | (uint64_t)v1;
+    return 1.1102230246251565e-16 + (double)v * 1.1102230246251565e-16;
+}
+static inline float lto_uniform_f32(lto_xorwow* s)
+{
+    uint32_t v = lto_xorwow_next(s);
+    return 2.3283064365386963e-10f + (float)v * 2.3283064365386963e-10f;
+}
+
+static inline void lto_atomic_add_f64(double* p, double v)
+{
+    uint64_t* q = (uint64_t*)p;
+    uint64_t old = __atomic_load_n(q, __ATOMIC_RELAXED), neu;
+    do {
+        double o; memcpy(&o, &old, 8); o += v; memcpy(&neu, &o, 8);
+    } while (!__atomic_compare_exchange_n(q, &old, neu, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+}
+
+/* PreComputedTriangle derived fields, S/primitives.py:99-112 (float64) */
+int lto_triangle_fields(const double* tris, size_t n, double* out)
+{
+    for (size_t i = 0; i < n; i++) {
+        const double* a = tris + i * 9; const double* b = a + 3; const double* c = a + 6;
+        double* o = out + i * 16;
+        double e1[3], e2[3], nn[3];
+        for (int k = 0; k < 3; k++) {
+            o[k] = (a[k] + b[k] + c[k]) / 3;   /* centroid :104 */
+            e1[k] = b[k] - a[k];               /* edge_1 :107 */
+            e2[k] = c[k] - a[k];               /* edge_2 :108 */
+        }
+        nn[0] = e1[1] * e2[2] - e1[2] * e2[1]; /* _normal :109 */
+        nn[1] = e1[2] * e2[0] - e1[0] * e2[2];
+        nn[2] = e1[0] * e2[1] - e1[1] * e2[0];
+        double num = a[0] * nn[0] + a[1] * nn[1] + a[2] * nn[2]; /* num :111 */
+        double l = sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+        for (int k = 0; k < 3; k++) { o[3 + k] = e1[k]; o[6 + k] = e2[k]; o[9 + k] = nn[k] / l; }
+        o[12] = num; o[13] = o[14] = o[15] = 0;
+    }
+    return 0;
+}
+
+/* ---- instantiate the precision-generic body ------------------------------ */
+#define R double
+#define SFX(n) n##_f64
+#define RLOG log
+#define RSIN sin
+#define RCOS cos
+#define RSQRT sqrt
+#define RFABS fabs
+#define RNEXT nextafter
+#include "lt_walk.inc"
+#undef R
+#undef SFX
+#undef RLOG
+#undef RSIN
+#undef RCOS
+#undef RSQRT
+#undef RFABS
+#undef RNEXT
+
+#define R float
+#define SFX(n) n##_f32
+#define RLOG logf
+#define RSIN sinf
+#define RCOS cosf
+#define RSQRT sqrtf
+#define RFABS fabsf
+#define RNEXT nextafterf
+#include "lt_walk.inc"
+#undef R
+#undef SFX
+
+/* ---- exports -------------------------------------------------------------- */
+int lto_run(const lto_scene* sc, uint64_t n_photons, uint64_t photon_offset, uint64_t seed,
+            const double* rng_table, uint64_t table_steps, int walk_f32, double* grid_f64,
+            uint64_t* grid_fx, lt_counters* counters, int n_threads)
+{
+    if (!sc || !counters) return LT_E_INVALID;
+    if ((sc->n_layers > 0) == (sc->n_tris > 0)) return LT_E_INVALID;
+    if (walk_f32 && rng_table) return LT_E_UNSUPPORTED;
+    return walk_f32
+        ? run_f32(sc, n_photons, photon_offset, seed, rng_table, table_steps, grid_f64, grid_fx, counters, n_threads)
+        : run_f64(sc, n_photons, photon_offset, seed, rng_table, table_steps, grid_f64, grid_fx, counters, n_threads);
+}
+
+int lto_rng_raw(uint64_t seed, uint64_t photon_id, uint32_t count, uint32_t* out)
+{
+    lto_xorwow s; lto_xorwow_seed(&s, lto_mix_seed(seed, photon_id));
+    for (uint32_t i = 0; i < count; i++) out[i] = lto_xorwow_next(&s);
+    return 0;
+}
+
+int lto_eval(int fn, const double* in, size_t n, double* out)
+{
+    for (size_t i = 0; i < n; i++) {
+        switch (fn) {
+        case LT_FN_HG_PDF: out[i] = hg_pdf_f64(in[2 * i], in[2 * i + 1]); break;
+        case LT_FN_HG_SAMPLE: out[i] = hg_sample_f64(in[2 * i], in[2 * i + 1]); break;
+        case LT_FN_ONB: onb_f64(in + 3 * i, out + 6 * i, out + 6 * i + 3); break;
+        case LT_FN_DISK: disk_f64(in[2 * i], in[2 * i + 1], out + 2 * i); break;
+        case LT_FN_COSINE_HEMI: cosine_hemi_f64(in + 8 * i, in + 8 * i + 3, in[8 * i + 6], in[8 * i + 7], out + 4 * i); break;
+        case LT_FN_REFLECT: reflect_f64(in + 6 * i, in + 6 * i + 3, out + 3 * i); break;
+        case LT_FN_BOUNDARY: {
+            double ct, refr[3];
+            out[5 * i] = boundary_f64(in + 8 * i, in + 8 * i + 3, in[8 * i + 6], in[8 * i + 7], &ct, refr);
+            out[5 * i + 1] = ct; out[5 * i + 2] = refr[0]; out[5 * i + 3] = refr[1]; out[5 * i + 4] = refr[2];
+        } break;
+        case LT_FN_SPIN: {
+            double u[3] = {in[5 * i], in[5 * i + 1], in[5 * i + 2]};
+            spin_f64(u, in[5 * i + 3], in[5 * i + 4]);
+            out[3 * i] = u[0]; out[3 * i + 1] = u[1]; out[3 * i + 2] = u[2];
+        } break;
+        default: return LT_E_INVALID;
+        }
+    }
+    return 0;
+}
+
+static void make_tri(const double* v9, tri_f64* T)
+{
+    double f[16]; lto_triangle_fields(v9, 1, f);
+    for (int k = 0; k < 3; k++) { T->a[k] = v9[k]; T->ab[k] = f[3 + k]; T->ac[k] = f[6 + k]; T->n[k] = f[9 + k]; }
+    T->med_front = T->med_back = -1;
+}
+
+int lto_triangle_intersect(const double* origins, const double* dirs, const double* tris, size_t n, double* t_out)
+{
+    for (size_t i = 0; i < n; i++) {
+        tri_f64 T; make_tri(tris + 9 * i, &T);
+        t_out[i] = tri_hit_f64(origins + 3 * i, dirs + 3 * i, &T);
+    }
+    return 0;
+}
+
+int lto_intersect_bounds(const double* origins, const double* dirs, const double* tmax,
+                         const double* boxes, size_t n, int32_t* hit_out)
+{
+    for (size_t i = 0; i < n; i++) {
+        const double* d = dirs + 3 * i;
+        double inv[3] = {1.0 / d[0], 1.0 / d[1], 1.0 / d[2]};
+        hit_out[i] = box_hit_f64(boxes + 6 * i, boxes + 6 * i + 3, origins + 3 * i, inv, tmax ? tmax[i] : INFINITY);
+    }
+    return 0;
+}
+
+int lto_intersect_rays(const lto_scene* sc, const double* origins, const double* dirs, const double* tmax,
+                       size_t n, int use_bvh, int32_t* prim_out, double* t_out)
+{
+    if (!sc || sc->n_tris <= 0) return LT_E_INVALID;
+    world_f64 W; prepare_f64(&W, sc);
+    for (size_t i = 0; i < n; i++) {
+        int pi; double t; double tm = tmax ? tmax[i] : INFINITY;
+        if (use_bvh) nearest_bvh_f64(W.tris, W.nodes, sc->n_nodes, origins + 3 * i, dirs + 3 * i, tm, &pi, &t);
+        else nearest_brute_f64(W.tris, sc->n_tris, origins + 3 * i, dirs + 3 * i, tm, &pi, &t);
+        prim_out[i] = pi; t_out[i] = t;
+    }
+    release_f64(&W);
+    return 0;
+}
