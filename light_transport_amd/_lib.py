@@ -1,0 +1,294 @@
+"""ctypes binding of liblt_hip.so (the C ABI declared in include/lt.h).
+
+The product has no CPU fallback: if the shared library or a gfx950 device is
+missing, every compute entry point raises ``LtError``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblt_hip.so")
+
+TALLY = {"f32": 0, "f64": 1, "u64fx": 2}
+TALLY_NP = {0: np.float32, 1: np.float64, 2: np.uint64}
+FX_SCALE = 2.0 ** 40
+SRC_PENCIL, SRC_COSINE_QUAD = 0, 1
+FLAG_F32_WALK = 1
+FN = dict(HG_PDF=0, HG_SAMPLE=1, ONB=2, DISK=3, COSINE_HEMI=4, REFLECT=5, BOUNDARY=6, SPIN=7)
+_FN_SHAPE = {0: (2, 1), 1: (2, 1), 2: (3, 6), 3: (2, 2), 4: (8, 4), 5: (6, 3), 6: (8, 5), 7: (5, 3)}
+
+# every symbol include/lt.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "lt_abi_version", "lt_create", "lt_destroy", "lt_last_error", "lt_set_media", "lt_set_layers", "lt_set_mesh",
+    "lt_set_grid", "lt_set_source", "lt_set_max_steps", "lt_set_launch_config", "lt_launch", "lt_sync",
+    "lt_last_kernel_ms", "lt_zero_tally", "lt_read_grid", "lt_read_grid_f64", "lt_read_counters",
+    "lt_grid_device_ptr", "lt_counters_device_ptr", "lt_stream", "lt_reduce_grid", "lt_intersect_rays",
+    "lt_triangle_intersect", "lt_intersect_bounds", "lt_eval", "lt_rng_raw", "lt_device_info",
+]
+
+
+class LtError(RuntimeError):
+    pass
+
+
+class Medium(C.Structure):
+    _fields_ = [("mu_a", C.c_double), ("mu_s", C.c_double), ("g", C.c_double), ("n", C.c_double)]
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("lo", C.c_double * 3), ("hi", C.c_double * 3), ("offset", C.c_int32),
+                ("n_prims", C.c_int32), ("axis", C.c_int32), ("pad_", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("photons", C.c_uint64), ("steps", C.c_uint64)] + [
+        (k, C.c_double) for k in ("w_absorbed", "w_lost_outside_grid", "w_escaped_top", "w_escaped_bottom",
+                                  "w_escaped_mesh", "w_specular", "w_roulette_net", "w_capped")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile liblt_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc")]
+    if not verbose:
+        cmd.append("-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LtError("liblt_hip.so is not built (run light_transport_amd.build() or "
+                          "`make -C light_transport_amd/csrc`); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.lt_last_error.restype = C.c_char_p
+        L.lt_last_error.argtypes = [C.c_void_p]
+        L.lt_stream.restype = C.c_void_p
+        L.lt_stream.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a.reshape(shape) if shape is not None else a
+
+
+class Context:
+    """One lt_ctx: one GPU, one HIP stream, one voxel grid."""
+
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        rc = lib().lt_create(C.byref(self._h), C.c_int(device_id))
+        if rc != 0:
+            msg = lib().lt_last_error(None)
+            raise LtError("lt_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        self.device_id = device_id
+        self._grid_shape = None
+        self._tally = None
+
+    # -- plumbing ---------------------------------------------------------
+    def _ck(self, rc, what):
+        if rc != 0:
+            msg = lib().lt_last_error(self._h)
+            raise LtError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().lt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- scene ------------------------------------------------------------
+    def set_media(self, media):
+        arr = (Medium * len(media))(*[Medium(*map(float, m)) for m in media])
+        self._ck(lib().lt_set_media(self._h, arr, C.c_int(len(media))), "lt_set_media")
+
+    def set_layers(self, z_bounds, medium_idx, n_above=1.0, n_below=1.0):
+        zb = _f64(z_bounds)
+        mi = np.ascontiguousarray(medium_idx, dtype=np.int32)
+        if zb.size != mi.size + 1:
+            raise LtError("set_layers: need len(z_bounds) == len(medium_idx) + 1")
+        self._ck(lib().lt_set_layers(self._h, _dp(zb), _ip(mi), C.c_int(mi.size), C.c_double(n_above),
+                                     C.c_double(n_below)), "lt_set_layers")
+
+    def set_mesh(self, verts, med_front, med_back, nodes):
+        v = _f64(verts).reshape(-1, 3, 3)
+        mf = np.ascontiguousarray(med_front, dtype=np.int32)
+        mb = np.ascontiguousarray(med_back, dtype=np.int32)
+        n = len(nodes["offset"])
+        arr = (BvhNode * max(n, 1))()
+        for i in range(n):
+            for k in range(3):
+                arr[i].lo[k] = float(nodes["lo"][i][k])
+                arr[i].hi[k] = float(nodes["hi"][i][k])
+            arr[i].offset = int(nodes["offset"][i])
+            arr[i].n_prims = int(nodes["n_prims"][i])
+            arr[i].axis = int(nodes["axis"][i])
+        if mf.size != v.shape[0] or mb.size != v.shape[0]:
+            raise LtError("set_mesh: medium arrays must have one entry per triangle")
+        self._ck(lib().lt_set_mesh(self._h, _dp(v), _ip(mf), _ip(mb), C.c_int(v.shape[0]), arr, C.c_int(n)),
+                 "lt_set_mesh")
+
+    def set_grid(self, shape, origin, voxel, dtype="f32"):
+        nx, ny, nz = (int(s) for s in shape)
+        o = (C.c_double * 3)(*map(float, origin))
+        vx = (C.c_double * 3)(*map(float, voxel))
+        t = TALLY[dtype] if isinstance(dtype, str) else int(dtype)
+        self._ck(lib().lt_set_grid(self._h, C.c_int(nx), C.c_int(ny), C.c_int(nz), o, vx, C.c_int(t)), "lt_set_grid")
+        self._grid_shape = (nz, ny, nx)
+        self._tally = t
+
+    def set_source(self, type=SRC_PENCIL, pos=(0, 0, 0), dir=(0, 0, 1), extra=None, start_medium=0):
+        p = (C.c_double * 3)(*map(float, pos))
+        d = (C.c_double * 3)(*map(float, dir))
+        ex = (C.c_double * 6)(*map(float, (list(extra) + [0.0] * 6)[:6])) if extra is not None else None
+        self._ck(lib().lt_set_source(self._h, C.c_int(type), p, d, ex, C.c_int(start_medium)), "lt_set_source")
+
+    def set_max_steps(self, n):
+        self._ck(lib().lt_set_max_steps(self._h, C.c_uint32(int(n))), "lt_set_max_steps")
+
+    def set_launch_config(self, blocks_per_cu=0, threads_per_block=0):
+        self._ck(lib().lt_set_launch_config(self._h, C.c_int(blocks_per_cu), C.c_int(threads_per_block)),
+                 "lt_set_launch_config")
+
+    # -- run --------------------------------------------------------------
+    def launch(self, n_photons, seed=0, photon_offset=0, rng_table=None, f32_walk=False):
+        tab, steps = None, 0
+        if rng_table is not None:
+            tab = _f64(rng_table)
+            if tab.ndim != 3 or tab.shape[0] != n_photons or tab.shape[2] != 4:
+                raise LtError("rng_table must have shape [n_photons, steps, 4]")
+            steps = tab.shape[1]
+        flags = FLAG_F32_WALK if f32_walk else 0
+        self._ck(lib().lt_launch(self._h, C.c_uint64(int(n_photons)), C.c_uint64(int(photon_offset)),
+                                 C.c_uint64(int(seed) & (2 ** 64 - 1)), _dp(tab), C.c_uint64(steps),
+                                 C.c_uint32(flags)), "lt_launch")
+
+    def sync(self):
+        self._ck(lib().lt_sync(self._h), "lt_sync")
+
+    def last_kernel_ms(self):
+        ms = C.c_double()
+        self._ck(lib().lt_last_kernel_ms(self._h, C.byref(ms)), "lt_last_kernel_ms")
+        return ms.value
+
+    def zero_tally(self):
+        self._ck(lib().lt_zero_tally(self._h), "lt_zero_tally")
+
+    # -- readback ---------------------------------------------------------
+    def read_grid_raw(self):
+        out = np.empty(self._grid_shape, dtype=TALLY_NP[self._tally])
+        self._ck(lib().lt_read_grid(self._h, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)), "lt_read_grid")
+        return out
+
+    def read_grid(self):
+        """Absorbed weight per voxel as float64 [nz, ny, nx]."""
+        out = np.empty(self._grid_shape, dtype=np.float64)
+        self._ck(lib().lt_read_grid_f64(self._h, _dp(out), C.c_size_t(out.size)), "lt_read_grid_f64")
+        return out
+
+    def read_counters(self):
+        c = Counters()
+        self._ck(lib().lt_read_counters(self._h, C.byref(c)), "lt_read_counters")
+        return c.as_dict()
+
+    def grid_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(lib().lt_grid_device_ptr(self._h, C.byref(p), C.byref(n)), "lt_grid_device_ptr")
+        return p.value, n.value
+
+    def counters_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(lib().lt_counters_device_ptr(self._h, C.byref(p), C.byref(n)), "lt_counters_device_ptr")
+        return p.value, n.value
+
+    def stream(self):
+        return lib().lt_stream(self._h)
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, mhz, mem = C.c_int(), C.c_int(), C.c_size_t()
+        self._ck(lib().lt_device_info(self._h, name, C.c_size_t(256), C.byref(cus), C.byref(mhz), C.byref(mem)),
+                 "lt_device_info")
+        return dict(name=name.value.decode(), cus=cus.value, clock_mhz=mhz.value, hbm_bytes=mem.value)
+
+    # -- device-side queries ----------------------------------------------
+    def intersect_rays(self, origins, dirs, tmax=None, use_bvh=True):
+        o, d = _f64(origins).reshape(-1, 3), _f64(dirs).reshape(-1, 3)
+        n = o.shape[0]
+        tm = None if tmax is None else np.ascontiguousarray(np.broadcast_to(tmax, (n,)), dtype=np.float64)
+        prim, t = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.float64)
+        self._ck(lib().lt_intersect_rays(self._h, _dp(o), _dp(d), _dp(tm), C.c_size_t(n), C.c_int(int(use_bvh)),
+                                         _ip(prim), _dp(t)), "lt_intersect_rays")
+        return prim, t
+
+    def triangle_intersect(self, origins, dirs, tris):
+        o, d, t = _f64(origins).reshape(-1, 3), _f64(dirs).reshape(-1, 3), _f64(tris).reshape(-1, 9)
+        out = np.empty(o.shape[0], dtype=np.float64)
+        self._ck(lib().lt_triangle_intersect(self._h, _dp(o), _dp(d), _dp(t), C.c_size_t(o.shape[0]), _dp(out)),
+                 "lt_triangle_intersect")
+        return out
+
+    def intersect_bounds(self, origins, dirs, boxes, tmax=None):
+        o, d, b = _f64(origins).reshape(-1, 3), _f64(dirs).reshape(-1, 3), _f64(boxes).reshape(-1, 6)
+        n = o.shape[0]
+        tm = None if tmax is None else np.ascontiguousarray(np.broadcast_to(tmax, (n,)), dtype=np.float64)
+        out = np.empty(n, dtype=np.int32)
+        self._ck(lib().lt_intersect_bounds(self._h, _dp(o), _dp(d), _dp(tm), _dp(b), C.c_size_t(n), _ip(out)),
+                 "lt_intersect_bounds")
+        return out
+
+    def eval(self, name, inp):
+        fn = FN[name]
+        k_in, k_out = _FN_SHAPE[fn]
+        a = _f64(inp).reshape(-1, k_in)
+        out = np.empty((a.shape[0], k_out), dtype=np.float64)
+        self._ck(lib().lt_eval(self._h, C.c_int(fn), _dp(a), C.c_size_t(a.shape[0]), _dp(out)), "lt_eval")
+        return out
+
+    def rng_raw(self, seed, photon_id, count):
+        out = np.empty(count, dtype=np.uint32)
+        self._ck(lib().lt_rng_raw(self._h, C.c_uint64(seed), C.c_uint64(photon_id), C.c_uint32(count),
+                                  out.ctypes.data_as(C.POINTER(C.c_uint32))), "lt_rng_raw")
+        return out
+
+
+_default_ctx = {}
+
+
+def default_context(device_id=0):
+    """Process-wide context per device, for the function-style API."""
+    ctx = _default_ctx.get(device_id)
+    if ctx is None:
+        ctx = _default_ctx[device_id] = Context(device_id)
+    return ctx

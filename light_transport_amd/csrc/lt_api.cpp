@@ -1,0 +1,728 @@
+// lt_api.cpp -- host side of the C ABI declared in include/lt.h.
+//
+// Built with -ffp-contract=off: the derived scene constants (1/mu_t, mu_a/mu_t,
+// triangle edges and normals) are single IEEE operations, as in the reference's
+// NumPy float64 code (e.g. primitives.py:105-111).
+//
+// There is no CPU fallback in this library: every compute entry point runs a
+// gfx950 kernel or fails.
+#include <hip/hip_runtime_api.h>
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "lt_internal.hpp"
+
+using namespace ltk;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    hipError_t ensure(size_t n)
+    {
+        if (n <= bytes && p) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&p, n ? n : 16);
+        if (e == hipSuccess) bytes = n ? n : 16;
+        return e;
+    }
+};
+
+}  // namespace
+
+struct lt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    hipDeviceProp_t prop;
+
+    // scene (host copies)
+    std::vector<lt_medium> media;
+    std::vector<double> z_bounds;
+    std::vector<int32_t> layer_medium;
+    double n_above = 1.0, n_below = 1.0;
+    std::vector<double> verts;
+    std::vector<int32_t> med_front, med_back;
+    std::vector<lt_bvh_node> nodes;
+    bool have_layers = false, have_mesh = false, have_grid = false, have_source = false;
+    int nx = 0, ny = 0, nz = 0, tally = LT_TALLY_F32;
+    double origin[3] = {0, 0, 0}, voxel[3] = {1, 1, 1};
+    int src_type = LT_SRC_PENCIL, start_medium = 0;
+    double src_pos[3] = {0, 0, 0}, src_dir[3] = {0, 0, 1}, src_extra[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t max_steps = 1000000;
+    int blocks_per_cu = 0, threads_per_block = 0;
+
+    // device buffers
+    DevBuf d_media[2], d_zb[2], d_lm, d_tris[2], d_nodes[2];  // [0]=f64, [1]=f32
+    DevBuf d_grid, d_counters, d_head, d_table, d_scratch_in, d_scratch_out, d_scratch_aux;
+    bool tables_dirty = true;
+    bool timed = false;
+
+    int fail(int code, const char* fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+    int hip(hipError_t e, const char* what)
+    {
+        if (e == hipSuccess) return LT_OK;
+        return fail(LT_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    }
+    size_t grid_elem() const { return tally == LT_TALLY_F32 ? 4 : 8; }
+    size_t n_vox() const { return (size_t)nx * (size_t)ny * (size_t)nz; }
+};
+
+#define CHECK_CTX(c) do { if (!(c)) return LT_E_INVALID; } while (0)
+#define HIP_TRY(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (c)->hip(e_, #call); } while (0)
+#define BIND(c) HIP_TRY(c, hipSetDevice((c)->device))
+
+namespace {
+
+template <typename R>
+void fill_media(const std::vector<lt_medium>& in, std::vector<MedD<R>>& out)
+{
+    out.resize(in.size());
+    for (size_t i = 0; i < in.size(); i++) {
+        const double mu_t = in[i].mu_a + in[i].mu_s;
+        MedD<R>& m = out[i];
+        m.mu_t = (R)mu_t;
+        m.inv_mu_t = (R)(mu_t > 0 ? 1.0 / mu_t : 0.0);
+        m.absorb = (R)(mu_t > 0 ? in[i].mu_a / mu_t : 0.0);
+        m.g = (R)in[i].g;
+        m.n = (R)in[i].n;
+        const R g = m.g;  // derived in walk precision, one operation each
+        m.one_m_g2 = (R)1 - g * g;
+        m.one_p_g2 = (R)1 + g * g;
+        m.inv_2g = g != 0 ? (R)1 / ((R)2 * g) : (R)0;
+    }
+}
+
+// PreComputedTriangle fields (primitives.py:105-111) in float64, then narrowed
+template <typename R>
+void fill_tris(const std::vector<double>& v, const std::vector<int32_t>& mf, const std::vector<int32_t>& mb,
+               std::vector<TriD<R>>& out)
+{
+    const size_t n = v.size() / 9;
+    out.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        const double* a = &v[9 * i];
+        const double* b = a + 3;
+        const double* c = a + 6;
+        double e1[3], e2[3], nn[3];
+        for (int k = 0; k < 3; k++) { e1[k] = b[k] - a[k]; e2[k] = c[k] - a[k]; }
+        nn[0] = e1[1] * e2[2] - e1[2] * e2[1];
+        nn[1] = e1[2] * e2[0] - e1[0] * e2[2];
+        nn[2] = e1[0] * e2[1] - e1[1] * e2[0];
+        const double l = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+        for (int k = 0; k < 3; k++) {
+            out[i].a[k] = (R)a[k]; out[i].ab[k] = (R)e1[k]; out[i].ac[k] = (R)e2[k]; out[i].n[k] = (R)(nn[k] / l);
+        }
+        out[i].med_front = mf[i];
+        out[i].med_back = mb[i];
+    }
+}
+
+template <typename R>
+void fill_nodes(const std::vector<lt_bvh_node>& in, std::vector<NodeD<R>>& out)
+{
+    out.resize(in.size());
+    for (size_t i = 0; i < in.size(); i++) {
+        for (int k = 0; k < 3; k++) {
+            R lo = (R)in[i].lo[k], hi = (R)in[i].hi[k];
+            // keep the box conservative when narrowing
+            if ((double)lo > in[i].lo[k]) lo = std::nextafter(lo, -std::numeric_limits<R>::infinity());
+            if ((double)hi < in[i].hi[k]) hi = std::nextafter(hi, std::numeric_limits<R>::infinity());
+            out[i].lo[k] = lo; out[i].hi[k] = hi;
+        }
+        out[i].offset = in[i].offset;
+        out[i].n_prims = in[i].n_prims;
+        out[i].axis = in[i].axis;
+        out[i].pad_ = 0;
+    }
+}
+
+template <typename T>
+int upload(lt_ctx* c, DevBuf& b, const std::vector<T>& h)
+{
+    HIP_TRY(c, b.ensure(h.size() * sizeof(T)));
+    if (!h.empty()) HIP_TRY(c, hipMemcpyAsync(b.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return LT_OK;
+}
+
+int upload_tables(lt_ctx* c)
+{
+    if (!c->tables_dirty) return LT_OK;
+    int rc;
+    // staging vectors live until the stream has drained (pageable H2D copies)
+    std::vector<MedD<double>> m64; std::vector<MedD<float>> m32;
+    std::vector<double> z64; std::vector<float> z32;
+    std::vector<TriD<double>> t64; std::vector<TriD<float>> t32;
+    std::vector<NodeD<double>> n64; std::vector<NodeD<float>> n32;
+    fill_media(c->media, m64); fill_media(c->media, m32);
+    if ((rc = upload(c, c->d_media[0], m64))) return rc;
+    if ((rc = upload(c, c->d_media[1], m32))) return rc;
+    if (c->have_layers) {
+        z64 = c->z_bounds;
+        z32.assign(z64.begin(), z64.end());
+        if ((rc = upload(c, c->d_zb[0], z64))) return rc;
+        if ((rc = upload(c, c->d_zb[1], z32))) return rc;
+        if ((rc = upload(c, c->d_lm, c->layer_medium))) return rc;
+    }
+    if (c->have_mesh) {
+        fill_tris(c->verts, c->med_front, c->med_back, t64);
+        fill_tris(c->verts, c->med_front, c->med_back, t32);
+        fill_nodes(c->nodes, n64); fill_nodes(c->nodes, n32);
+        if ((rc = upload(c, c->d_tris[0], t64))) return rc;
+        if ((rc = upload(c, c->d_tris[1], t32))) return rc;
+        if ((rc = upload(c, c->d_nodes[0], n64))) return rc;
+        if ((rc = upload(c, c->d_nodes[1], n32))) return rc;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->tables_dirty = false;
+    return LT_OK;
+}
+
+// depth of the flattened tree (bounds the traversal stack) + structural checks
+int bvh_depth(const std::vector<lt_bvh_node>& n, int n_tris, int idx, int depth, int* max_depth, int* visited)
+{
+    if (idx < 0 || idx >= (int)n.size() || depth > 64) return -1;
+    (*visited)++;
+    if (depth > *max_depth) *max_depth = depth;
+    const lt_bvh_node& nd = n[idx];
+    if (nd.n_prims > 0) {
+        if (nd.offset < 0 || nd.offset + nd.n_prims > n_tris) return -1;
+        return 0;
+    }
+    if (nd.axis < 0 || nd.axis > 2 || nd.offset <= idx + 1) return -1;
+    if (bvh_depth(n, n_tris, idx + 1, depth + 1, max_depth, visited)) return -1;
+    return bvh_depth(n, n_tris, nd.offset, depth + 1, max_depth, visited);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lt_abi_version(void) { return LT_ABI_VERSION; }
+
+const char* lt_last_error(const lt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int lt_create(lt_ctx** out, int device_id)
+{
+    if (!out) return LT_E_INVALID;
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        g_create_error = std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "0 devices") +
+                         "); this library has no CPU fallback";
+        return LT_E_HIP;
+    }
+    if (device_id < 0 || device_id >= n_dev) { g_create_error = "device_id out of range"; return LT_E_INVALID; }
+    lt_ctx* c = new (std::nothrow) lt_ctx();
+    if (!c) { g_create_error = "out of host memory"; return LT_E_NOMEM; }
+    c->device = device_id;
+    e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&c->prop, device_id);
+    if (e == hipSuccess && std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("device arch ") + c->prop.gcnArchName + " is not gfx950: kernels are built for MI355X only";
+        delete c;
+        return LT_E_UNSUPPORTED;
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = c->d_counters.ensure(sizeof(DevCounters));
+    if (e == hipSuccess) e = c->d_head.ensure(sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), c->stream);
+    if (e != hipSuccess) {
+        g_create_error = std::string("lt_create: ") + hipGetErrorString(e);
+        delete c;
+        return LT_E_HIP;
+    }
+    *out = c;
+    return LT_OK;
+}
+
+int lt_destroy(lt_ctx* c)
+{
+    if (!c) return LT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 2; i++) { c->d_media[i].release(); c->d_zb[i].release(); c->d_tris[i].release(); c->d_nodes[i].release(); }
+    c->d_lm.release(); c->d_grid.release(); c->d_counters.release(); c->d_head.release(); c->d_table.release();
+    c->d_scratch_in.release(); c->d_scratch_out.release(); c->d_scratch_aux.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return LT_OK;
+}
+
+int lt_set_media(lt_ctx* c, const lt_medium* media, int n)
+{
+    CHECK_CTX(c);
+    if (!media || n <= 0 || n > kMaxMedia) return c->fail(LT_E_INVALID, "lt_set_media: need 1..%d media", kMaxMedia);
+    for (int i = 0; i < n; i++) {
+        const lt_medium& m = media[i];
+        if (!(m.mu_a >= 0) || !(m.mu_s >= 0) || !(m.g > -1 && m.g < 1) || !(m.n > 0) || !std::isfinite(m.mu_a + m.mu_s))
+            return c->fail(LT_E_INVALID, "lt_set_media: medium %d out of range (mu_a,mu_s >= 0, |g| < 1, n > 0)", i);
+    }
+    c->media.assign(media, media + n);
+    c->tables_dirty = true;
+    return LT_OK;
+}
+
+int lt_set_layers(lt_ctx* c, const double* z_bounds, const int32_t* medium_idx, int n, double n_above, double n_below)
+{
+    CHECK_CTX(c);
+    if (!z_bounds || !medium_idx || n <= 0 || n > kMaxLayers)
+        return c->fail(LT_E_INVALID, "lt_set_layers: need 1..%d layers", kMaxLayers);
+    if (!std::isfinite(z_bounds[0])) return c->fail(LT_E_INVALID, "lt_set_layers: z_bounds[0] must be finite");
+    for (int i = 0; i < n; i++) {
+        if (!(z_bounds[i + 1] > z_bounds[i])) return c->fail(LT_E_INVALID, "lt_set_layers: z_bounds must ascend");
+        if (medium_idx[i] < 0) return c->fail(LT_E_INVALID, "lt_set_layers: negative medium index");
+    }
+    if (!(n_above > 0) || !(n_below > 0)) return c->fail(LT_E_INVALID, "lt_set_layers: ambient indices must be > 0");
+    c->z_bounds.assign(z_bounds, z_bounds + n + 1);
+    c->layer_medium.assign(medium_idx, medium_idx + n);
+    c->n_above = n_above; c->n_below = n_below;
+    c->have_layers = true; c->have_mesh = false;
+    c->tables_dirty = true;
+    return LT_OK;
+}
+
+int lt_set_mesh(lt_ctx* c, const double* verts, const int32_t* med_front, const int32_t* med_back, int n_tris,
+                const lt_bvh_node* nodes, int n_nodes)
+{
+    CHECK_CTX(c);
+    if (!verts || !med_front || !med_back || n_tris <= 0 || !nodes || n_nodes <= 0)
+        return c->fail(LT_E_INVALID, "lt_set_mesh: empty mesh or BVH");
+    for (size_t i = 0; i < (size_t)n_tris * 9; i++)
+        if (!std::isfinite(verts[i])) return c->fail(LT_E_INVALID, "lt_set_mesh: non-finite vertex");
+    std::vector<lt_bvh_node> nn(nodes, nodes + n_nodes);
+    int depth = 0, visited = 0;
+    if (bvh_depth(nn, n_tris, 0, 0, &depth, &visited) != 0 || visited != n_nodes)
+        return c->fail(LT_E_INVALID, "lt_set_mesh: BVH is not a valid pre-order tree over %d triangles", n_tris);
+    if (depth >= 31) return c->fail(LT_E_UNSUPPORTED, "lt_set_mesh: BVH depth %d exceeds the traversal stack (31)", depth);
+    size_t covered = 0;
+    for (const auto& nd : nn) if (nd.n_prims > 0) covered += (size_t)nd.n_prims;
+    if (covered != (size_t)n_tris) return c->fail(LT_E_INVALID, "lt_set_mesh: leaves cover %zu of %d triangles", covered, n_tris);
+    c->verts.assign(verts, verts + (size_t)n_tris * 9);
+    c->med_front.assign(med_front, med_front + n_tris);
+    c->med_back.assign(med_back, med_back + n_tris);
+    c->nodes.swap(nn);
+    c->have_mesh = true; c->have_layers = false;
+    c->tables_dirty = true;
+    return LT_OK;
+}
+
+int lt_set_grid(lt_ctx* c, int nx, int ny, int nz, const double origin[3], const double voxel[3], int tally_dtype)
+{
+    CHECK_CTX(c);
+    if (nx <= 0 || ny <= 0 || nz <= 0 || !origin || !voxel) return c->fail(LT_E_INVALID, "lt_set_grid: bad shape");
+    if (tally_dtype < LT_TALLY_F32 || tally_dtype > LT_TALLY_U64FX) return c->fail(LT_E_INVALID, "lt_set_grid: bad tally dtype");
+    for (int k = 0; k < 3; k++)
+        if (!(voxel[k] > 0) || !std::isfinite(origin[k])) return c->fail(LT_E_INVALID, "lt_set_grid: bad origin/voxel");
+    if ((double)nx * ny * nz > 2147483647.0) return c->fail(LT_E_UNSUPPORTED, "lt_set_grid: more than 2^31-1 voxels");
+    BIND(c);
+    c->nx = nx; c->ny = ny; c->nz = nz; c->tally = tally_dtype;
+    for (int k = 0; k < 3; k++) { c->origin[k] = origin[k]; c->voxel[k] = voxel[k]; }
+    HIP_TRY(c, c->d_grid.ensure(c->n_vox() * c->grid_elem()));
+    c->have_grid = true;
+    return lt_zero_tally(c);
+}
+
+int lt_set_source(lt_ctx* c, int type, const double pos[3], const double dir[3], const double* extra, int start_medium)
+{
+    CHECK_CTX(c);
+    if (!pos || !dir || (type != LT_SRC_PENCIL && type != LT_SRC_COSINE_QUAD)) return c->fail(LT_E_INVALID, "lt_set_source: bad arguments");
+    const double l = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    if (!(l > 0) || !std::isfinite(l)) return c->fail(LT_E_INVALID, "lt_set_source: zero direction");
+    if (type == LT_SRC_COSINE_QUAD && !extra) return c->fail(LT_E_INVALID, "lt_set_source: quad source needs extra[6]");
+    c->src_type = type; c->start_medium = start_medium;
+    for (int k = 0; k < 3; k++) { c->src_pos[k] = pos[k]; c->src_dir[k] = dir[k] / l; }
+    for (int k = 0; k < 6; k++) c->src_extra[k] = extra ? extra[k] : 0.0;
+    c->have_source = true;
+    return LT_OK;
+}
+
+int lt_set_max_steps(lt_ctx* c, uint32_t max_steps)
+{
+    CHECK_CTX(c);
+    if (max_steps == 0) return c->fail(LT_E_INVALID, "lt_set_max_steps: must be > 0");
+    c->max_steps = max_steps;
+    return LT_OK;
+}
+
+int lt_set_launch_config(lt_ctx* c, int blocks_per_cu, int threads_per_block)
+{
+    CHECK_CTX(c);
+    if (blocks_per_cu < 0 || threads_per_block < 0 || threads_per_block > 256 || (threads_per_block % 64) != 0)
+        return c->fail(LT_E_INVALID, "lt_set_launch_config: threads must be a multiple of 64, <= 256");
+    c->blocks_per_cu = blocks_per_cu; c->threads_per_block = threads_per_block;
+    return LT_OK;
+}
+
+int lt_zero_tally(lt_ctx* c)
+{
+    CHECK_CTX(c);
+    BIND(c);
+    if (c->have_grid) HIP_TRY(c, hipMemsetAsync(c->d_grid.p, 0, c->n_vox() * c->grid_elem(), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), c->stream));
+    return LT_OK;
+}
+
+int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t seed, const double* rng_table,
+              uint64_t table_steps, uint32_t flags)
+{
+    CHECK_CTX(c);
+    if (c->media.empty()) return c->fail(LT_E_STATE, "lt_launch: lt_set_media first");
+    if (!c->have_layers && !c->have_mesh) return c->fail(LT_E_STATE, "lt_launch: lt_set_layers or lt_set_mesh first");
+    if (!c->have_grid) return c->fail(LT_E_STATE, "lt_launch: lt_set_grid first");
+    if (!c->have_source) return c->fail(LT_E_STATE, "lt_launch: lt_set_source first");
+    const int n_media = (int)c->media.size();
+    if (c->have_layers) {
+        for (int32_t m : c->layer_medium) if (m >= n_media) return c->fail(LT_E_INVALID, "lt_launch: layer medium index %d >= %d media", m, n_media);
+    } else {
+        for (size_t i = 0; i < c->med_front.size(); i++)
+            if (c->med_front[i] >= n_media || c->med_back[i] >= n_media || c->med_front[i] < -1 || c->med_back[i] < -1)
+                return c->fail(LT_E_INVALID, "lt_launch: triangle %zu medium index out of range", i);
+        if (c->start_medium < 0 || c->start_medium >= n_media) return c->fail(LT_E_INVALID, "lt_launch: start_medium out of range");
+    }
+    Variant v;
+    v.f32 = (flags & LT_FLAG_F32_WALK) ? 1 : 0;
+    v.mesh = c->have_mesh ? 1 : 0;
+    v.table = rng_table ? 1 : 0;
+    v.tally = c->tally;
+    if (v.table && v.f32) return c->fail(LT_E_UNSUPPORTED, "lt_launch: table RNG runs the f64 walk only");
+    if (v.table && v.tally == LT_TALLY_F32) return c->fail(LT_E_UNSUPPORTED, "lt_launch: table RNG needs an f64 or u64fx tally");
+    if (v.table && table_steps == 0) return c->fail(LT_E_INVALID, "lt_launch: table_steps == 0");
+    BIND(c);
+    int rc = upload_tables(c);
+    if (rc) return rc;
+    if (n_photons == 0) { c->timed = false; return LT_OK; }
+
+    if (v.table) {
+        const size_t bytes = (size_t)n_photons * (size_t)table_steps * 4 * sizeof(double);
+        HIP_TRY(c, c->d_table.ensure(bytes));
+        HIP_TRY(c, hipMemcpyAsync(c->d_table.p, rng_table, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller may free rng_table on return
+    }
+
+    WalkParams P;
+    std::memset(&P, 0, sizeof P);
+    P.head = (unsigned long long*)c->d_head.p;
+    P.n_photons = n_photons; P.photon_offset = photon_offset; P.seed = seed;
+    const int pi = v.f32 ? 1 : 0;
+    P.media = c->d_media[pi].p; P.zb = c->d_zb[pi].p; P.layer_medium = (const int32_t*)c->d_lm.p;
+    P.tris = c->d_tris[pi].p; P.nodes = c->d_nodes[pi].p;
+    P.n_media = n_media;
+    P.n_layers = c->have_layers ? (int)c->layer_medium.size() : 0;
+    P.n_tris = c->have_mesh ? (int)c->med_front.size() : 0;
+    P.n_nodes = c->have_mesh ? (int)c->nodes.size() : 0;
+    P.n_above = c->n_above; P.n_below = c->n_below;
+    P.grid = c->d_grid.p; P.nx = c->nx; P.ny = c->ny; P.nz = c->nz; P.tally = c->tally;
+    for (int k = 0; k < 3; k++) {
+        P.origin[k] = c->origin[k]; P.inv_voxel[k] = 1.0 / c->voxel[k];
+        P.src_pos[k] = c->src_pos[k]; P.src_dir[k] = c->src_dir[k];
+        P.src_e1[k] = c->src_extra[k]; P.src_e2[k] = c->src_extra[3 + k];
+    }
+    P.src_type = c->src_type; P.start_medium = c->start_medium;
+    P.table = (const double*)c->d_table.p; P.table_steps = table_steps;
+    P.max_steps = c->max_steps;
+    P.counters = (DevCounters*)c->d_counters.p;
+
+    LaunchCfg cfg;
+    cfg.threads = c->threads_per_block > 0 ? c->threads_per_block : 256;
+    cfg.lds_bytes = walk_lds_bytes(v, P.n_media, P.n_layers, P.n_tris, P.n_nodes);
+    if (cfg.lds_bytes > 160 * 1024)
+        return c->fail(LT_E_UNSUPPORTED, "lt_launch: scene tables need %zu B of LDS (> 160 KiB per CU)", cfg.lds_bytes);
+    int resident = walk_max_blocks_per_cu(v, cfg.threads, cfg.lds_bytes);
+    if (resident <= 0) return c->fail(LT_E_HIP, "lt_launch: kernel variant not resident (occupancy query returned %d)", resident);
+    int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : resident;
+    // persistent threads: no more workgroups than photons can feed
+    unsigned long long want = (n_photons + (unsigned long long)cfg.threads - 1) / (unsigned long long)cfg.threads;
+    unsigned long long cap = (unsigned long long)per_cu * (unsigned long long)c->prop.multiProcessorCount;
+    cfg.blocks = (int)(want < cap ? want : cap);
+    if (cfg.blocks < 1) cfg.blocks = 1;
+
+    HIP_TRY(c, hipMemsetAsync(c->d_head.p, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(c, launch_walk(P, v, cfg, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return LT_OK;
+}
+
+int lt_sync(lt_ctx* c)
+{
+    CHECK_CTX(c);
+    BIND(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_last_kernel_ms(lt_ctx* c, double* ms)
+{
+    CHECK_CTX(c);
+    if (!ms) return c->fail(LT_E_INVALID, "lt_last_kernel_ms: null output");
+    if (!c->timed) return c->fail(LT_E_STATE, "lt_last_kernel_ms: no launch recorded");
+    BIND(c);
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    float f = 0;
+    HIP_TRY(c, hipEventElapsedTime(&f, c->ev0, c->ev1));
+    *ms = (double)f;
+    return LT_OK;
+}
+
+int lt_read_grid(lt_ctx* c, void* host_out, size_t bytes)
+{
+    CHECK_CTX(c);
+    if (!c->have_grid) return c->fail(LT_E_STATE, "lt_read_grid: no grid");
+    if (!host_out || bytes != c->n_vox() * c->grid_elem())
+        return c->fail(LT_E_INVALID, "lt_read_grid: expected %zu bytes", c->n_vox() * c->grid_elem());
+    BIND(c);
+    HIP_TRY(c, hipMemcpyAsync(host_out, c->d_grid.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_read_grid_f64(lt_ctx* c, double* host_out, size_t n_voxels)
+{
+    CHECK_CTX(c);
+    if (!c->have_grid) return c->fail(LT_E_STATE, "lt_read_grid_f64: no grid");
+    if (!host_out || n_voxels != c->n_vox()) return c->fail(LT_E_INVALID, "lt_read_grid_f64: expected %zu voxels", c->n_vox());
+    BIND(c);
+    if (c->tally == LT_TALLY_F64) return lt_read_grid(c, host_out, n_voxels * 8);
+    HIP_TRY(c, c->d_scratch_out.ensure(n_voxels * sizeof(double)));
+    HIP_TRY(c, launch_grid_to_f64(c->d_grid.p, c->tally, n_voxels, (double*)c->d_scratch_out.p, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(host_out, c->d_scratch_out.p, n_voxels * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_read_counters(lt_ctx* c, lt_counters* out)
+{
+    CHECK_CTX(c);
+    if (!out) return c->fail(LT_E_INVALID, "lt_read_counters: null output");
+    BIND(c);
+    DevCounters h;
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d_counters.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->photons = h.photons; out->steps = h.steps;
+    out->w_absorbed = h.w[CW_ABSORBED]; out->w_lost_outside_grid = h.w[CW_LOST];
+    out->w_escaped_top = h.w[CW_ESC_TOP]; out->w_escaped_bottom = h.w[CW_ESC_BOT];
+    out->w_escaped_mesh = h.w[CW_ESC_MESH]; out->w_specular = h.w[CW_SPECULAR];
+    out->w_roulette_net = h.w[CW_ROULETTE]; out->w_capped = h.w[CW_CAPPED];
+    return LT_OK;
+}
+
+int lt_grid_device_ptr(lt_ctx* c, void** ptr, size_t* bytes)
+{
+    CHECK_CTX(c);
+    if (!c->have_grid) return c->fail(LT_E_STATE, "lt_grid_device_ptr: no grid");
+    if (ptr) *ptr = c->d_grid.p;
+    if (bytes) *bytes = c->n_vox() * c->grid_elem();
+    return LT_OK;
+}
+
+int lt_counters_device_ptr(lt_ctx* c, void** ptr, size_t* bytes)
+{
+    CHECK_CTX(c);
+    if (ptr) *ptr = c->d_counters.p;
+    if (bytes) *bytes = sizeof(DevCounters);
+    return LT_OK;
+}
+
+void* lt_stream(lt_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---- RCCL (loaded lazily; no link-time dependency) ------------------------
+namespace {
+typedef int (*nccl_allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_reduce_t)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
+typedef int (*nccl_group_t)(void);
+struct Rccl {
+    void* h = nullptr; nccl_allreduce_t allreduce = nullptr; nccl_reduce_t reduce = nullptr;
+    nccl_group_t gstart = nullptr, gend = nullptr;
+} g_rccl;
+// ncclDataType_t / ncclRedOp_t values (nccl.h): ncclUint64 = 5, ncclFloat32 = 7, ncclFloat64 = 8, ncclSum = 0
+enum { kNcclUint64 = 5, kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0 };
+}  // namespace
+
+int lt_reduce_grid(lt_ctx* c, void* comm, int root)
+{
+    CHECK_CTX(c);
+    if (!comm) return c->fail(LT_E_INVALID, "lt_reduce_grid: null communicator");
+    if (!c->have_grid) return c->fail(LT_E_STATE, "lt_reduce_grid: no grid");
+    if (!g_rccl.h) {
+        g_rccl.h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!g_rccl.h) g_rccl.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!g_rccl.h) return c->fail(LT_E_UNSUPPORTED, "lt_reduce_grid: cannot load librccl.so: %s", dlerror());
+        g_rccl.allreduce = (nccl_allreduce_t)dlsym(g_rccl.h, "ncclAllReduce");
+        g_rccl.reduce = (nccl_reduce_t)dlsym(g_rccl.h, "ncclReduce");
+        g_rccl.gstart = (nccl_group_t)dlsym(g_rccl.h, "ncclGroupStart");
+        g_rccl.gend = (nccl_group_t)dlsym(g_rccl.h, "ncclGroupEnd");
+        if (!g_rccl.allreduce || !g_rccl.reduce || !g_rccl.gstart || !g_rccl.gend)
+            return c->fail(LT_E_UNSUPPORTED, "lt_reduce_grid: librccl.so lacks ncclAllReduce/ncclReduce");
+    }
+    BIND(c);
+    const int dt = c->tally == LT_TALLY_F32 ? kNcclFloat32 : (c->tally == LT_TALLY_F64 ? kNcclFloat64 : kNcclUint64);
+    DevCounters* dc = (DevCounters*)c->d_counters.p;
+    int rc = g_rccl.gstart();
+    if (root < 0) {
+        if (!rc) rc = g_rccl.allreduce(c->d_grid.p, c->d_grid.p, c->n_vox(), dt, kNcclSum, comm, c->stream);
+        if (!rc) rc = g_rccl.allreduce(&dc->photons, &dc->photons, 2, kNcclUint64, kNcclSum, comm, c->stream);
+        if (!rc) rc = g_rccl.allreduce(dc->w, dc->w, 8, kNcclFloat64, kNcclSum, comm, c->stream);
+    } else {
+        if (!rc) rc = g_rccl.reduce(c->d_grid.p, c->d_grid.p, c->n_vox(), dt, kNcclSum, root, comm, c->stream);
+        if (!rc) rc = g_rccl.reduce(&dc->photons, &dc->photons, 2, kNcclUint64, kNcclSum, root, comm, c->stream);
+        if (!rc) rc = g_rccl.reduce(dc->w, dc->w, 8, kNcclFloat64, kNcclSum, root, comm, c->stream);
+    }
+    int rc2 = g_rccl.gend();
+    if (rc || rc2) return c->fail(LT_E_HIP, "lt_reduce_grid: RCCL error %d", rc ? rc : rc2);
+    return LT_OK;
+}
+
+// ---- device-side queries ---------------------------------------------------
+namespace {
+int stage_in(lt_ctx* c, DevBuf& b, const void* h, size_t bytes)
+{
+    HIP_TRY(c, b.ensure(bytes));
+    HIP_TRY(c, hipMemcpyAsync(b.p, h, bytes, hipMemcpyHostToDevice, c->stream));
+    return LT_OK;
+}
+}  // namespace
+
+int lt_intersect_rays(lt_ctx* c, const double* origins, const double* dirs, const double* tmax, size_t n, int use_bvh,
+                      int32_t* prim_out, double* t_out)
+{
+    CHECK_CTX(c);
+    if (!c->have_mesh) return c->fail(LT_E_STATE, "lt_intersect_rays: lt_set_mesh first");
+    if (n == 0) return LT_OK;
+    if (!origins || !dirs || !prim_out || !t_out) return c->fail(LT_E_INVALID, "lt_intersect_rays: null argument");
+    BIND(c);
+    if (c->media.empty()) { lt_medium m = {0, 0, 0, 1}; c->media.push_back(m); }
+    int rc = upload_tables(c);
+    if (rc) return rc;
+    // layout of the staging buffer: origins | dirs | tmax
+    const size_t vb = n * 3 * sizeof(double), tb = n * sizeof(double);
+    HIP_TRY(c, c->d_scratch_in.ensure(2 * vb + tb));
+    char* base = (char*)c->d_scratch_in.p;
+    HIP_TRY(c, hipMemcpyAsync(base, origins, vb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(base + vb, dirs, vb, hipMemcpyHostToDevice, c->stream));
+    if (tmax) HIP_TRY(c, hipMemcpyAsync(base + 2 * vb, tmax, tb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, c->d_scratch_out.ensure(tb));
+    HIP_TRY(c, c->d_scratch_aux.ensure(n * sizeof(int32_t)));
+    HIP_TRY(c, launch_intersect_rays(c->d_tris[0].p, c->d_nodes[0].p, (int)c->med_front.size(), (int)c->nodes.size(),
+                                     (const double*)base, (const double*)(base + vb),
+                                     tmax ? (const double*)(base + 2 * vb) : nullptr, n, use_bvh,
+                                     (int32_t*)c->d_scratch_aux.p, (double*)c->d_scratch_out.p, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(prim_out, c->d_scratch_aux.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(t_out, c->d_scratch_out.p, tb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_triangle_intersect(lt_ctx* c, const double* origins, const double* dirs, const double* tris, size_t n, double* t_out)
+{
+    CHECK_CTX(c);
+    if (n == 0) return LT_OK;
+    if (!origins || !dirs || !tris || !t_out) return c->fail(LT_E_INVALID, "lt_triangle_intersect: null argument");
+    BIND(c);
+    const size_t vb = n * 3 * sizeof(double), qb = n * 9 * sizeof(double);
+    HIP_TRY(c, c->d_scratch_in.ensure(2 * vb + qb));
+    char* base = (char*)c->d_scratch_in.p;
+    HIP_TRY(c, hipMemcpyAsync(base, origins, vb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(base + vb, dirs, vb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(base + 2 * vb, tris, qb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, c->d_scratch_out.ensure(n * sizeof(double)));
+    HIP_TRY(c, launch_triangle_intersect((const double*)base, (const double*)(base + vb), (const double*)(base + 2 * vb), n,
+                                         (double*)c->d_scratch_out.p, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(t_out, c->d_scratch_out.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_intersect_bounds(lt_ctx* c, const double* origins, const double* dirs, const double* tmax, const double* boxes,
+                        size_t n, int32_t* hit_out)
+{
+    CHECK_CTX(c);
+    if (n == 0) return LT_OK;
+    if (!origins || !dirs || !boxes || !hit_out) return c->fail(LT_E_INVALID, "lt_intersect_bounds: null argument");
+    BIND(c);
+    const size_t vb = n * 3 * sizeof(double), bb = n * 6 * sizeof(double), tb = n * sizeof(double);
+    HIP_TRY(c, c->d_scratch_in.ensure(2 * vb + bb + tb));
+    char* base = (char*)c->d_scratch_in.p;
+    HIP_TRY(c, hipMemcpyAsync(base, origins, vb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(base + vb, dirs, vb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(base + 2 * vb, boxes, bb, hipMemcpyHostToDevice, c->stream));
+    if (tmax) HIP_TRY(c, hipMemcpyAsync(base + 2 * vb + bb, tmax, tb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, c->d_scratch_aux.ensure(n * sizeof(int32_t)));
+    HIP_TRY(c, launch_intersect_bounds((const double*)base, (const double*)(base + vb),
+                                       tmax ? (const double*)(base + 2 * vb + bb) : nullptr,
+                                       (const double*)(base + 2 * vb), n, (int32_t*)c->d_scratch_aux.p, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hit_out, c->d_scratch_aux.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_eval(lt_ctx* c, int fn, const double* in, size_t n, double* out)
+{
+    CHECK_CTX(c);
+    static const int k_in[8] = {2, 2, 3, 2, 8, 6, 8, 5}, k_out[8] = {1, 1, 6, 2, 4, 3, 5, 3};
+    if (fn < 0 || fn > 7) return c->fail(LT_E_INVALID, "lt_eval: unknown function %d", fn);
+    if (n == 0) return LT_OK;
+    if (!in || !out) return c->fail(LT_E_INVALID, "lt_eval: null argument");
+    BIND(c);
+    int rc = stage_in(c, c->d_scratch_in, in, n * k_in[fn] * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(c, c->d_scratch_out.ensure(n * k_out[fn] * sizeof(double)));
+    HIP_TRY(c, launch_eval(fn, (const double*)c->d_scratch_in.p, n, (double*)c->d_scratch_out.p, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch_out.p, n * k_out[fn] * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_rng_raw(lt_ctx* c, uint64_t seed, uint64_t photon_id, uint32_t count, uint32_t* out)
+{
+    CHECK_CTX(c);
+    if (count == 0) return LT_OK;
+    if (!out) return c->fail(LT_E_INVALID, "lt_rng_raw: null output");
+    BIND(c);
+    HIP_TRY(c, c->d_scratch_aux.ensure((size_t)count * 4));
+    HIP_TRY(c, launch_rng_raw(seed, photon_id, count, (uint32_t*)c->d_scratch_aux.p, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch_aux.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_device_info(lt_ctx* c, char* name, size_t name_len, int* n_cus, int* clock_mhz, size_t* hbm_bytes)
+{
+    CHECK_CTX(c);
+    if (name && name_len) { std::snprintf(name, name_len, "%s (%s)", c->prop.name, c->prop.gcnArchName); }
+    if (n_cus) *n_cus = c->prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = c->prop.clockRate / 1000;
+    if (hbm_bytes) *hbm_bytes = c->prop.totalGlobalMem;
+    return LT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// lt_internal.hpp -- layouts shared by the host API (lt_api.cpp, g++) and the
+// gfx950 kernels (lt_kernels.hip, hipcc).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "../../include/lt.h"
+
+namespace ltk {
+
+// Per-medium constants in walk precision R.  Derived values are computed on the
+// host in double, one IEEE operation each, then narrowed -- the same recipe as
+// the oracle, so both sides start from identical bits.
+template <typename R>
+struct MedD {
+    R mu_t, inv_mu_t, absorb, g;
+    R n, one_m_g2, one_p_g2, inv_2g;
+};
+
+// Triangle record: role of PreComputedTriangle (primitives.py:99-112).
+template <typename R>
+struct TriD {
+    R a[3], ab[3], ac[3], n[3];
+    int32_t med_front, med_back;
+};
+
+// Flattened BVH node: role of LinearBVHNode (bvh_new.py:60-67).
+template <typename R>
+struct NodeD {
+    R lo[3], hi[3];
+    int32_t offset, n_prims, axis, pad_;
+};
+
+struct DevCounters {
+    unsigned long long photons, steps;
+    double w[8];  // absorbed, lost, esc_top, esc_bot, esc_mesh, specular, roulette, capped
+};
+enum { CW_ABSORBED = 0, CW_LOST, CW_ESC_TOP, CW_ESC_BOT, CW_ESC_MESH, CW_SPECULAR, CW_ROULETTE, CW_CAPPED };
+
+constexpr int kMaxMedia = 32;
+constexpr int kMaxLayers = 64;
+
+struct WalkParams {
+    // photon queue
+    unsigned long long* head;
+    unsigned long long n_photons, photon_offset, seed;
+    // scene tables (device pointers, element type depends on walk precision)
+    const void* media;
+    const void* zb;
+    const int32_t* layer_medium;
+    const void* tris;
+    const void* nodes;
+    int n_media, n_layers, n_tris, n_nodes;
+    double n_above, n_below;
+    // voxel grid
+    void* grid;
+    int nx, ny, nz, tally;
+    double origin[3], inv_voxel[3];
+    // source
+    int src_type, start_medium;
+    double src_pos[3], src_dir[3], src_e1[3], src_e2[3];
+    // table RNG
+    const double* table;
+    unsigned long long table_steps;
+    unsigned max_steps;
+    DevCounters* counters;
+};
+
+struct LaunchCfg {
+    int blocks, threads;
+    size_t lds_bytes;
+};
+
+// walk variants: precision x geometry x rng are compile-time, tally is too
+struct Variant {
+    int f32;     // 0: f64 walk, 1: f32 walk
+    int mesh;    // 0: layered slab, 1: triangle mesh + BVH
+    int table;   // 0: XORWOW, 1: table RNG
+    int tally;   // LT_TALLY_*
+};
+
+hipError_t launch_walk(const WalkParams& P, const Variant& v, const LaunchCfg& cfg, hipStream_t s);
+size_t walk_lds_bytes(const Variant& v, int n_media, int n_layers, int n_tris, int n_nodes);
+// resident-blocks-per-CU the runtime reports for a variant at `threads`
+int walk_max_blocks_per_cu(const Variant& v, int threads, size_t lds_bytes);
+
+hipError_t launch_intersect_rays(const void* tris, const void* nodes, int n_tris, int n_nodes,
+                                 const double* o, const double* d, const double* tmax, size_t n,
+                                 int use_bvh, int32_t* prim, double* t, hipStream_t s);
+hipError_t launch_triangle_intersect(const double* o, const double* d, const double* tris, size_t n,
+                                     double* t, hipStream_t s);
+hipError_t launch_intersect_bounds(const double* o, const double* d, const double* tmax,
+                                   const double* boxes, size_t n, int32_t* hit, hipStream_t s);
+hipError_t launch_eval(int fn, const double* in, size_t n, double* out, hipStream_t s);
+hipError_t launch_rng_raw(unsigned long long seed, unsigned long long photon_id, unsigned count,
+                          uint32_t* out, hipStream_t s);
+hipError_t launch_grid_to_f64(const void* grid, int tally, size_t n, double* out, hipStream_t s);
+
+}  // namespace ltk

@@ -1,0 +1,841 @@
+// lt_kernels.hip -- gfx950 (CDNA4) kernels of the photon-transport hot path.
+//
+// Design:
+//   * one wavefront lane per live photon; photon state lives in VGPRs;
+//   * persistent threads: the grid is sized to the resident capacity of the
+//     chip and every wave loops, pulling PACKETS of photon ids from one global
+//     counter (1 returning atomic per 64 photons) -- divergent path lengths are
+//     absorbed by refilling dead lanes, not by launching more threads;
+//   * dead lanes are found with a wave ballot and refilled by ballot rank
+//     (v_mbcnt), so a wave only idles lanes in the final drain;
+//   * rocRAND XORWOW state per lane, re-seeded per photon from (seed, id) so a
+//     photon's uniforms do not depend on which lane / wave / GPU traces it;
+//   * media, layer and BVH/triangle tables are staged once per workgroup into
+//     LDS (all lanes read the same few entries: LDS broadcast);
+//   * energy is deposited with no-return global atomics (f32 / f64 / u64
+//     fixed point); rare per-photon events go to LDS counters.
+// No MFMA: there is no dense contraction anywhere on this path.
+//
+// Reference citations: S/ = LightTransportSimulator/light_transport/src/.
+#include <hip/hip_runtime.h>
+
+#define ROCRAND_DETAIL_BM_NOT_IN_STATE
+#include <rocrand/rocrand_xorwow.h>
+#include <rocrand/rocrand_uniform.h>
+
+#include "lt_internal.hpp"
+
+namespace ltk {
+
+#define LT_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------
+// precision traits
+// ---------------------------------------------------------------------------
+template <typename R> struct Mx;
+template <> struct Mx<double> {
+    static LT_DEV double log(double x) { return ::log(x); }
+    static LT_DEV double sqrt(double x) { return ::sqrt(x); }
+    static LT_DEV double abs(double x) { return ::fabs(x); }
+    static LT_DEV double sin(double x) { return ::sin(x); }
+    static LT_DEV double cos(double x) { return ::cos(x); }
+    // sin/cos of 2*pi*xi without a range reduction by pi
+    static LT_DEV void sincos_turn(double xi, double* s, double* c) { ::sincospi(2.0 * xi, s, c); }
+    static LT_DEV double inf() { return __builtin_huge_val(); }
+    static LT_DEV double uniform(rocrand_state_xorwow* st) { return rocrand_uniform_double(st); }
+};
+template <> struct Mx<float> {
+    static LT_DEV float log(float x) { return ::logf(x); }
+    static LT_DEV float sqrt(float x) { return ::sqrtf(x); }
+    static LT_DEV float abs(float x) { return ::fabsf(x); }
+    static LT_DEV float sin(float x) { return ::sinf(x); }
+    static LT_DEV float cos(float x) { return ::cosf(x); }
+    static LT_DEV void sincos_turn(float xi, float* s, float* c) { ::sincospif(2.0f * xi, s, c); }
+    static LT_DEV float inf() { return __builtin_huge_valf(); }
+    static LT_DEV float uniform(rocrand_state_xorwow* st) { return rocrand_uniform(st); }
+};
+
+template <typename R> LT_DEV R dot3(const R* a, const R* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <typename R> LT_DEV void cross3(const R* a, const R* b, R* o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+template <typename R> LT_DEV void normalize3(R* v)  // S/vectors.py:6-7
+{
+    R l = Mx<R>::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    v[0] /= l; v[1] /= l; v[2] /= l;
+}
+
+// ---------------------------------------------------------------------------
+// geometry queries
+// ---------------------------------------------------------------------------
+// Moller-Trumbore: triangle_intersect, S/intersects.py:46-104.  NaN == None.
+template <typename R>
+LT_DEV R tri_hit(const R* o, const R* d, const TriD<R>* T)
+{
+    const R eps = (R)1e-7;  // :56
+    const R nan = (R)__builtin_nanf("");
+    R n[3] = {T->n[0], T->n[1], T->n[2]};
+    R ddn = dot3(d, n);
+    if (Mx<R>::abs(ddn) <= eps) return nan;  // :69-72
+    R ab[3] = {T->ab[0], T->ab[1], T->ab[2]};
+    R ac[3] = {T->ac[0], T->ac[1], T->ac[2]};
+    R pvec[3], qvec[3], tvec[3];
+    cross3(d, ac, pvec);              // :74
+    R det = dot3(ab, pvec);           // :77
+    if (-eps < det && det < eps) return nan;  // :79
+    R inv_det = (R)1 / det;
+    tvec[0] = o[0] - T->a[0]; tvec[1] = o[1] - T->a[1]; tvec[2] = o[2] - T->a[2];
+    R u = dot3(tvec, pvec) * inv_det;  // :86
+    if (u < 0 || u > 1) return nan;
+    cross3(tvec, ab, qvec);            // :91
+    R v = dot3(d, qvec) * inv_det;     // :94
+    if (v < 0 || u + v > 1) return nan;
+    R t = dot3(ac, qvec) * inv_det;    // :99
+    return (t > eps) ? t : nan;        // :101-104
+}
+
+// 1 + 2*gamma(3) with float32 machine epsilon, S/intersects.py:229-235
+template <typename R> LT_DEV R box_widen()
+{
+    const R eps = (R)5.9604644775390625e-08;
+    return (R)1 + (R)2 * (((R)3 * eps) / ((R)1 - (R)3 * eps));
+}
+
+// intersect_bounds, S/intersects.py:179-196
+template <typename R>
+LT_DEV bool box_hit(const R* lo, const R* hi, const R* o, const R* inv_d, R tmax)
+{
+    R t0 = 0, t1 = tmax;
+    const R widen = box_widen<R>();
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        R tn = (lo[i] - o[i]) * inv_d[i];
+        R tf = (hi[i] - o[i]) * inv_d[i];
+        if (tn > tf) { R s = tn; tn = tf; tf = s; }
+        tf *= widen;
+        t0 = tn > t0 ? tn : t0;
+        t1 = tf < t1 ? tf : t1;
+        if (t0 > t1) return false;
+    }
+    return true;
+}
+
+// nearest-hit bookkeeping: predicate EPSILON < t < min_distance
+// (S/bvh_new.py:438); equal t -> lower primitive index (what a brute-force
+// scan in index order returns; the reference traversal's bug B3 is not kept).
+template <typename R>
+LT_DEV void consider(const TriD<R>* tris, int i, const R* o, const R* d, int& bi, R& bt)
+{
+    R t = tri_hit(o, d, &tris[i]);
+    if (t == t && t > (R)1e-6) {
+        if (t < bt || (t == bt && bi >= 0 && i < bi)) { bt = t; bi = i; }
+    }
+}
+
+constexpr int kStack = 32;
+
+template <typename R>
+LT_DEV void nearest_bvh(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes, const R* o,
+                        const R* d, R tmax, int& prim, R& t_out)
+{
+    int bi = -1; R bt = tmax;
+    if (n_nodes > 0) {
+        R inv_d[3] = {(R)1 / d[0], (R)1 / d[1], (R)1 / d[2]};  // S/bvh_new.py:418
+        const bool neg[3] = {inv_d[0] < 0, inv_d[1] < 0, inv_d[2] < 0};
+        const R slack = box_widen<R>();
+        int stack[kStack]; int sp = 0; int cur = 0;
+        for (;;) {
+            const NodeD<R>* nd = &nodes[cur];
+            R lo[3] = {nd->lo[0], nd->lo[1], nd->lo[2]};
+            R hi[3] = {nd->hi[0], nd->hi[1], nd->hi[2]};
+            if (box_hit(lo, hi, o, inv_d, bt * slack)) {
+                const int np = nd->n_prims, off = nd->offset;
+                if (np > 0) {
+                    for (int k = 0; k < np; k++) consider(tris, off + k, o, d, bi, bt);
+                    if (sp == 0) break;
+                    cur = stack[--sp];
+                } else if (neg[nd->axis]) {  // S/bvh_new.py:455-458
+                    stack[sp++] = cur + 1; cur = off;
+                } else {
+                    stack[sp++] = off; cur = cur + 1;
+                }
+            } else {
+                if (sp == 0) break;
+                cur = stack[--sp];
+            }
+        }
+    }
+    prim = bi; t_out = bi >= 0 ? bt : Mx<R>::inf();
+}
+
+template <typename R>
+LT_DEV void nearest_brute(const TriD<R>* tris, int n_tris, const R* o, const R* d, R tmax,
+                          int& prim, R& t_out)
+{
+    int bi = -1; R bt = tmax;
+    for (int i = 0; i < n_tris; i++) consider(tris, i, o, d, bi, bt);
+    prim = bi; t_out = bi >= 0 ? bt : Mx<R>::inf();
+}
+
+// ---------------------------------------------------------------------------
+// sampling
+// ---------------------------------------------------------------------------
+// henyey_greenstein, S/medium_samples.py:14-16
+template <typename R> LT_DEV R hg_pdf(R cos_t, R g)
+{
+    R denom = (R)1 + g * g + (R)2 * g * cos_t;
+    return (R)0.07957747154594767 * ((R)1 - g * g) / (denom * Mx<R>::sqrt(denom));
+}
+
+// HG inverse CDF, deflection-angle convention
+template <typename R> LT_DEV R hg_sample(R xi, R g, R one_m_g2, R one_p_g2, R inv_2g)
+{
+    R c;
+    if (g == 0) c = (R)2 * xi - (R)1;
+    else {
+        R t = one_m_g2 / ((R)1 - g + (R)2 * g * xi);
+        c = (one_p_g2 - t * t) * inv_2g;
+    }
+    c = c > 1 ? (R)1 : c;
+    c = c < -1 ? (R)-1 : c;
+    return c;
+}
+
+// create_orthonormal_system, S/utils.py:72-80
+template <typename R> LT_DEV void onb(const R* n, R* v2, R* v3)
+{
+    if (Mx<R>::abs(n[0]) > Mx<R>::abs(n[1])) {
+        R l = Mx<R>::sqrt(n[0] * n[0] + n[2] * n[2]);
+        v2[0] = -n[2] / l; v2[1] = 0; v2[2] = n[0] / l;
+    } else {
+        R l = Mx<R>::sqrt(n[1] * n[1] + n[2] * n[2]);
+        v2[0] = 0; v2[1] = n[2] / l; v2[2] = -n[1] / l;
+    }
+    cross3(n, v2, v3);
+}
+
+// concentric_sample_disk, S/utils.py:115-128
+template <typename R> LT_DEV void disk(R u0, R u1, R* d)
+{
+    R ox = (R)2 * u0 - (R)1, oy = (R)2 * u1 - (R)1;
+    if (ox == 0 && oy == 0) { d[0] = 0; d[1] = 0; return; }
+    R r, theta;
+    if (Mx<R>::abs(ox) > Mx<R>::abs(oy)) { r = ox; theta = (R)0.7853981633974483 * (oy / ox); }
+    else { r = oy; theta = (R)1.5707963267948966 - (R)0.7853981633974483 * (ox / oy); }
+    d[0] = r * Mx<R>::cos(theta); d[1] = r * Mx<R>::sin(theta);
+}
+
+// cosine_weighted_hemisphere_sampling, S/utils.py:132-161
+template <typename R> LT_DEV void cosine_hemi(const R* n, const R* wi_in, R u0, R u1, R* out)
+{
+    R wiz = -wi_in[2];  // :133
+    R d[2]; disk(u0, u1, d);
+    R zz = (R)1 - d[0] * d[0] - d[1] * d[1];
+    R z = Mx<R>::sqrt(zz > 0 ? zz : (R)0);  // :138
+    R oz = z;
+    R v2[3], v3[3]; onb(n, v2, v3);
+    if (wiz < 0) oz = -oz;  // :145-146
+    R pdf = (wiz * oz > 0) ? Mx<R>::abs(z) * (R)0.3183098861837907 : (R)0;  // :149-152
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[k] = d[0] * v2[k] + d[1] * v3[k] + oz * n[k];  // :154-157
+    out[3] = pdf;
+}
+
+// get_reflected_direction, S/brdf.py:8-9
+template <typename R> LT_DEV void reflect(const R* v, const R* n, R* o)
+{
+    R k = (R)2 * dot3(v, n);
+    o[0] = v[0] - k * n[0]; o[1] = v[1] - k * n[1]; o[2] = v[2] - k * n[2];
+    normalize3(o);
+}
+
+// Dielectric boundary (App. C.5): exact unpolarised Fresnel + the refraction
+// vector of S/path_tracing_fix1.py:107-114 with Nr = n1/n2; TIR when the
+// radicand <= 0 (:110).  nf faces the incoming photon.
+template <typename R> LT_DEV R boundary(const R* d, const R* nf, R n1, R n2, R* cos_t_out, R* refr)
+{
+    R cos_i = -dot3(d, nf);
+    if (n1 == n2) {
+        *cos_t_out = cos_i; refr[0] = d[0]; refr[1] = d[1]; refr[2] = d[2];
+        return 0;
+    }
+    R Nr = n1 / n2;
+    R rad = (R)1 - Nr * Nr * ((R)1 - cos_i * cos_i);
+    if (rad <= 0) { *cos_t_out = 0; refr[0] = refr[1] = refr[2] = 0; return 1; }
+    R cos_t = Mx<R>::sqrt(rad);
+    R a = n1 * cos_i, b = n2 * cos_t, c = n1 * cos_t, e = n2 * cos_i;
+    R rs = (a - b) / (a + b), rp = (c - e) / (c + e);
+    R k = Nr * cos_i - cos_t;
+    refr[0] = d[0] * Nr + nf[0] * k;
+    refr[1] = d[1] * Nr + nf[1] * k;
+    refr[2] = d[2] * Nr + nf[2] * k;
+    normalize3(refr);
+    *cos_t_out = cos_t;
+    return (R)0.5 * (rs * rs + rp * rp);
+}
+
+// Spin (App. C.6): MCML direction update, |uz| > 0.99999 special case.
+template <typename R> LT_DEV void spin(R* u, R ct, R xi_phi)
+{
+    R st2 = (R)1 - ct * ct;
+    R st = Mx<R>::sqrt(st2 > 0 ? st2 : (R)0);
+    R sp, cp; Mx<R>::sincos_turn(xi_phi, &sp, &cp);
+    R ux = u[0], uy = u[1], uz = u[2];
+    if (Mx<R>::abs(uz) > (R)0.99999) {
+        u[0] = st * cp; u[1] = st * sp; u[2] = uz >= 0 ? ct : -ct;
+    } else {
+        R t2 = (R)1 - uz * uz;
+        R tmp = Mx<R>::sqrt(t2);
+        u[0] = st * (ux * uz * cp - uy * sp) / tmp + ux * ct;
+        u[1] = st * (uy * uz * cp + ux * sp) / tmp + uy * ct;
+        u[2] = -st * cp * tmp + uz * ct;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// RNG: rocRAND XORWOW, one stream per photon
+// ---------------------------------------------------------------------------
+LT_DEV unsigned long long mix_seed(unsigned long long seed, unsigned long long photon_id)
+{   // splitmix64 finaliser over (seed, photon id)
+    unsigned long long z = seed + (photon_id + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// ---------------------------------------------------------------------------
+// tally
+// ---------------------------------------------------------------------------
+template <int TALLY, typename R> LT_DEV void tally_add(void* grid, size_t idx, R dw)
+{
+    if constexpr (TALLY == LT_TALLY_F32) {
+        __hip_atomic_fetch_add(reinterpret_cast<float*>(grid) + idx, (float)dw, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    } else if constexpr (TALLY == LT_TALLY_F64) {
+        __hip_atomic_fetch_add(reinterpret_cast<double*>(grid) + idx, (double)dw, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        unsigned long long q = (unsigned long long)((double)dw * LT_FX_SCALE + 0.5);
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(grid) + idx, q, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LDS image of the scene tables
+// ---------------------------------------------------------------------------
+LT_DEV size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+template <typename R> struct LdsLayout {
+    size_t off_cnt, off_media, off_zb, off_lm, off_tris, off_nodes, total;
+    __host__ __device__ LdsLayout(int n_media, int n_layers, int n_tris, int n_nodes)
+    {
+        auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+        size_t o = 0;
+        off_cnt = o;   o = al(o + 8 * sizeof(double));
+        off_media = o; o = al(o + (size_t)n_media * sizeof(MedD<R>));
+        off_zb = o;    o = al(o + (size_t)(n_layers + 1) * sizeof(R));
+        off_lm = o;    o = al(o + (size_t)(n_layers > 0 ? n_layers : 1) * sizeof(int32_t));
+        off_tris = o;  o = al(o + (size_t)n_tris * sizeof(TriD<R>));
+        off_nodes = o; o = al(o + (size_t)n_nodes * sizeof(NodeD<R>));
+        total = o;
+    }
+};
+
+LT_DEV void lds_copy(void* dst, const void* src, size_t bytes)
+{
+    // tables are small (KBs); dword copies, all threads of the workgroup
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    for (size_t i = threadIdx.x; i < bytes / 4; i += blockDim.x) d[i] = s[i];
+}
+
+LT_DEV unsigned long long readlane64(unsigned long long v, int lane)
+{
+    unsigned lo = __builtin_amdgcn_readlane((unsigned)v, lane);
+    unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <typename T> LT_DEV T wave_sum(T v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+constexpr unsigned kPacket = 64;  // photon ids taken from the global queue per atomic
+
+// ---------------------------------------------------------------------------
+// the walk kernel
+// ---------------------------------------------------------------------------
+template <typename R, bool MESH, bool TABLE, int TALLY>
+__global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const LdsLayout<R> L(P.n_media, P.n_layers, P.n_tris, P.n_nodes);
+    double* s_cnt = reinterpret_cast<double*>(lds_raw + L.off_cnt);
+    const MedD<R>* s_med = reinterpret_cast<const MedD<R>*>(lds_raw + L.off_media);
+    const R* s_zb = reinterpret_cast<const R*>(lds_raw + L.off_zb);
+    const int32_t* s_lm = reinterpret_cast<const int32_t*>(lds_raw + L.off_lm);
+    const TriD<R>* s_tris = reinterpret_cast<const TriD<R>*>(lds_raw + L.off_tris);
+    const NodeD<R>* s_nodes = reinterpret_cast<const NodeD<R>*>(lds_raw + L.off_nodes);
+
+    if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0.0;
+    lds_copy(lds_raw + L.off_media, P.media, (size_t)P.n_media * sizeof(MedD<R>));
+    if constexpr (!MESH) {
+        lds_copy(lds_raw + L.off_zb, P.zb, (size_t)(P.n_layers + 1) * sizeof(R));
+        lds_copy(lds_raw + L.off_lm, P.layer_medium, (size_t)P.n_layers * sizeof(int32_t));
+    } else {
+        lds_copy(lds_raw + L.off_tris, P.tris, (size_t)P.n_tris * sizeof(TriD<R>));
+        lds_copy(lds_raw + L.off_nodes, P.nodes, (size_t)P.n_nodes * sizeof(NodeD<R>));
+    }
+    __syncthreads();
+
+    const R eps = (R)1e-6;  // EPSILON, S/constants.py:12
+    const R inf = Mx<R>::inf();
+    const int lane = threadIdx.x & 63;
+
+    // per-lane photon state
+    bool alive = false;
+    R px = 0, py = 0, pz = 0, ux = 0, uy = 0, uz = 1, w = 0, sleft = 0;
+    int cur = 0;
+    unsigned step = 0, max_steps = P.max_steps;
+    unsigned long long pid = 0, grp = 0;
+    rocrand_state_xorwow rng;
+    // per-lane accumulators of the frequent events
+    double acc_abs = 0.0, acc_lost = 0.0;
+    unsigned long long acc_steps = 0;
+    // wave-level packet of photon ids [pk_next, pk_end)
+    unsigned long long pk_next = 0, pk_end = 0;
+    bool q_done = false;
+
+    const R gx0 = (R)P.origin[0], gy0 = (R)P.origin[1], gz0 = (R)P.origin[2];
+    const R ivx = (R)P.inv_voxel[0], ivy = (R)P.inv_voxel[1], ivz = (R)P.inv_voxel[2];
+    const R fnx = (R)P.nx, fny = (R)P.ny, fnz = (R)P.nz;
+
+    for (;;) {
+        // ---------------- refill dead lanes (ballot + rank) ----------------
+        unsigned long long need = __ballot(!alive);
+        if (need != 0ull && !(q_done && pk_next >= pk_end)) {
+            const unsigned cnt = (unsigned)__popcll(need);
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32),
+                                      __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            const unsigned long long avail = pk_end - pk_next;
+            unsigned long long nlo = 0, nhi = 0;
+            if (cnt > avail && !q_done) {
+                const int leader = __ffsll((long long)need) - 1;
+                unsigned long long base = 0;
+                if (lane == leader)
+                    base = __hip_atomic_fetch_add(P.head, (unsigned long long)kPacket, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+                base = readlane64(base, leader);
+                nlo = base < P.n_photons ? base : P.n_photons;
+                nhi = base + kPacket < P.n_photons ? base + kPacket : P.n_photons;
+                if (nhi >= P.n_photons) q_done = true;
+            }
+            bool got = false;
+            unsigned long long id = 0;
+            if (!alive) {
+                if (rank < avail) { id = pk_next + rank; got = true; }
+                else if (rank - avail < nhi - nlo) { id = nlo + (rank - avail); got = true; }
+            }
+            if (cnt <= avail) pk_next += cnt;
+            else {
+                unsigned long long used = cnt - avail;
+                if (used > nhi - nlo) used = nhi - nlo;
+                pk_next = nlo + used; pk_end = nhi;
+            }
+
+            if (got) {
+                // ------------- emission: role of sample_light, S/light_samples.py:90-116
+                pid = P.photon_offset + id;
+                alive = true; w = 1; sleft = 0; step = 0; grp = 0;
+                max_steps = P.max_steps;
+                if constexpr (!TABLE) rocrand_init(mix_seed(P.seed, pid), 0ull, 0ull, &rng);
+                if (P.src_type == LT_SRC_COSINE_QUAD) {
+                    R u4[4];
+                    if constexpr (TABLE) {
+                        const double* t = P.table + (id * P.table_steps + grp) * 4;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) u4[k] = (R)(1.0 - t[k]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) u4[k] = Mx<R>::uniform(&rng);
+                    }
+                    grp++;
+                    R nrm[3] = {(R)P.src_dir[0], (R)P.src_dir[1], (R)P.src_dir[2]};
+                    R wi[3] = {-nrm[0], -nrm[1], -nrm[2]};
+                    R o4[4];
+                    cosine_hemi(nrm, wi, u4[2], u4[3], o4);
+                    ux = o4[0]; uy = o4[1]; uz = o4[2];
+                    px = (R)P.src_pos[0] + u4[0] * (R)P.src_e1[0] + u4[1] * (R)P.src_e2[0] + eps * o4[0];  // :96
+                    py = (R)P.src_pos[1] + u4[0] * (R)P.src_e1[1] + u4[1] * (R)P.src_e2[1] + eps * o4[1];
+                    pz = (R)P.src_pos[2] + u4[0] * (R)P.src_e1[2] + u4[1] * (R)P.src_e2[2] + eps * o4[2];
+                } else {
+                    px = (R)P.src_pos[0]; py = (R)P.src_pos[1]; pz = (R)P.src_pos[2];
+                    ux = (R)P.src_dir[0]; uy = (R)P.src_dir[1]; uz = (R)P.src_dir[2];
+                }
+                if constexpr (!MESH) {
+                    cur = -1;
+                    for (int l = 0; l < P.n_layers; l++)
+                        if (pz >= s_zb[l] && pz < s_zb[l + 1]) { cur = l; break; }
+                    if (cur < 0) {
+                        atomicAdd(&s_cnt[CW_ESC_TOP], (double)w); alive = false;
+                    } else if (P.src_type == LT_SRC_PENCIL && pz == s_zb[0] && uz > 0) {
+                        R n2 = s_med[s_lm[0]].n, n1 = (R)P.n_above;
+                        if (n1 != n2) {  // specular reflection on entering the first layer
+                            R d[3] = {ux, uy, uz}, nf[3] = {0, 0, -1}, ct, refr[3];
+                            R Rs = boundary(d, nf, n1, n2, &ct, refr);
+                            atomicAdd(&s_cnt[CW_SPECULAR], (double)(w * Rs));
+                            w -= w * Rs;
+                            if (!(w > 0)) alive = false;
+                            ux = refr[0]; uy = refr[1]; uz = refr[2];
+                        }
+                    }
+                } else {
+                    cur = P.start_medium;
+                }
+                if constexpr (TABLE) {
+                    unsigned long long cap = P.table_steps > grp ? P.table_steps - grp : 0ull;
+                    if (cap < (unsigned long long)max_steps) max_steps = (unsigned)cap;
+                }
+            }
+        }
+        if (!__any(alive)) break;  // wave-uniform: queue drained and every lane done
+
+        // ---------------- one photon-step ----------------
+        if (alive) {
+            if (step >= max_steps) {
+                atomicAdd(&s_cnt[CW_CAPPED], (double)w); alive = false;
+            } else {
+                step++;
+                acc_steps++;
+                R u4[4];
+                if constexpr (TABLE) {  // table RNG: S/scene.py:68-69, S/path_tracing_fix1.py:28-29
+                    const double* t = P.table + ((pid - P.photon_offset) * P.table_steps + grp) * 4;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) u4[k] = (R)(1.0 - t[k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) u4[k] = Mx<R>::uniform(&rng);
+                }
+                grp++;
+                const MedD<R>* Mp = &s_med[MESH ? cur : s_lm[cur]];
+                const R mu_t = Mp->mu_t;
+                if (sleft == 0) sleft = -Mx<R>::log(u4[0]);
+                const R s = (mu_t > 0) ? sleft * Mp->inv_mu_t : inf;
+
+                // ---- hop: distance to the next boundary ----
+                R tb = inf; int hit_tri = -1;
+                if constexpr (!MESH) {
+                    if (uz > 0) tb = (s_zb[cur + 1] - pz) / uz;
+                    else if (uz < 0) tb = (s_zb[cur] - pz) / uz;
+                } else {
+                    R o[3] = {px, py, pz}, d[3] = {ux, uy, uz}, th;
+                    nearest_bvh(s_tris, s_nodes, P.n_nodes, o, d, s, hit_tri, th);
+                    if (hit_tri >= 0) tb = th;
+                }
+                const bool at_boundary = MESH ? (hit_tri >= 0) : (tb <= s);
+                if (!at_boundary && !(s < inf)) {
+                    atomicAdd(&s_cnt[MESH ? CW_ESC_MESH : CW_CAPPED], (double)w); alive = false;
+                } else if (at_boundary) {
+                    px += ux * tb; py += uy * tb; pz += uz * tb;
+                    sleft -= tb * mu_t;
+                    if (!(sleft > 0)) sleft = 0;
+                    R nf[3], n1 = Mp->n, n2; int next;
+                    if constexpr (!MESH) {
+                        const bool down = uz > 0;
+                        pz = down ? s_zb[cur + 1] : s_zb[cur];
+                        nf[0] = 0; nf[1] = 0; nf[2] = down ? (R)-1 : (R)1;
+                        next = down ? cur + 1 : cur - 1;
+                        if (next < 0) n2 = (R)P.n_above;
+                        else if (next >= P.n_layers) n2 = (R)P.n_below;
+                        else n2 = s_med[s_lm[next]].n;
+                    } else {
+                        const TriD<R>* T = &s_tris[hit_tri];
+                        R tn[3] = {T->n[0], T->n[1], T->n[2]};
+                        R d[3] = {ux, uy, uz};
+                        R dn = dot3(d, tn);
+                        R sg = dn > 0 ? (R)-1 : (R)1;  // S/path_tracing_fix1.py:48-51
+                        nf[0] = sg * tn[0]; nf[1] = sg * tn[1]; nf[2] = sg * tn[2];
+                        next = dn > 0 ? T->med_front : T->med_back;
+                        n2 = next >= 0 ? s_med[next].n : n1;  // exterior: index matched
+                    }
+                    R d[3] = {ux, uy, uz}, ct, refr[3];
+                    R Rf = boundary(d, nf, n1, n2, &ct, refr);
+                    if (u4[3] <= Rf) {  // reflect: S/brdf.py:8-9
+                        R ro[3]; reflect(d, nf, ro);
+                        ux = ro[0]; uy = ro[1]; uz = ro[2];
+                        if constexpr (MESH) { px += eps * nf[0]; py += eps * nf[1]; pz += eps * nf[2]; }  // :118
+                    } else {
+                        const bool gone = MESH ? (next < 0) : (next < 0 || next >= P.n_layers);
+                        if (gone) {
+                            const int slot = MESH ? CW_ESC_MESH : (next < 0 ? CW_ESC_TOP : CW_ESC_BOT);
+                            atomicAdd(&s_cnt[slot], (double)w); alive = false;
+                        } else {
+                            ux = refr[0]; uy = refr[1]; uz = refr[2];
+                            if constexpr (MESH) { px -= eps * nf[0]; py -= eps * nf[1]; pz -= eps * nf[2]; }  // :112
+                            cur = next;
+                        }
+                    }
+                } else {
+                    // ---- interaction site: move, drop, spin, roulette ----
+                    px += ux * s; py += uy * s; pz += uz * s;
+                    sleft = 0;
+                    const R dw = w * Mp->absorb;
+                    const R fx = (px - gx0) * ivx, fy = (py - gy0) * ivy, fz = (pz - gz0) * ivz;
+                    if (fx >= 0 && fx < fnx && fy >= 0 && fy < fny && fz >= 0 && fz < fnz) {
+                        size_t idx = ((size_t)(int)fz * (size_t)P.ny + (size_t)(int)fy) * (size_t)P.nx + (size_t)(int)fx;
+                        tally_add<TALLY, R>(P.grid, idx, dw);
+                        acc_abs += (double)dw;
+                    } else {
+                        acc_lost += (double)dw;
+                    }
+                    w -= dw;
+                    if (!(w > 0)) alive = false;
+                    else {
+                        R u[3] = {ux, uy, uz};
+                        spin(u, hg_sample(u4[1], Mp->g, Mp->one_m_g2, Mp->one_p_g2, Mp->inv_2g), u4[2]);
+                        ux = u[0]; uy = u[1]; uz = u[2];
+                        if (w < (R)1e-4) {  // weight roulette; shape of S/path_tracing_fix1.py:126-132
+                            if (u4[3] <= (R)0.1) { atomicAdd(&s_cnt[CW_ROULETTE], -9.0 * (double)w); w *= (R)10; }
+                            else { atomicAdd(&s_cnt[CW_ROULETTE], (double)w); alive = false; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---------------- flush counters ----------------
+    const double wa = wave_sum(acc_abs), wl = wave_sum(acc_lost);
+    const unsigned long long ws = wave_sum(acc_steps);
+    if (lane == 0) {
+        atomicAdd(&s_cnt[CW_ABSORBED], wa);
+        atomicAdd(&s_cnt[CW_LOST], wl);
+        __hip_atomic_fetch_add(&P.counters->steps, ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 8)
+        __hip_atomic_fetch_add(&P.counters->photons, P.n_photons, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 8)
+        __hip_atomic_fetch_add(&P.counters->w[threadIdx.x], s_cnt[threadIdx.x], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------
+// variant dispatch
+// ---------------------------------------------------------------------------
+typedef void (*WalkFn)(const WalkParams);
+
+template <typename R, bool MESH, bool TABLE>
+static WalkFn pick_tally(int tally)
+{
+    switch (tally) {
+    case LT_TALLY_F32: if constexpr (!TABLE) return walk_kernel<R, MESH, TABLE, LT_TALLY_F32>; else return nullptr;
+    case LT_TALLY_F64: return walk_kernel<R, MESH, TABLE, LT_TALLY_F64>;
+    case LT_TALLY_U64FX: return walk_kernel<R, MESH, TABLE, LT_TALLY_U64FX>;
+    }
+    return nullptr;
+}
+
+static WalkFn pick(const Variant& v)
+{
+    if (v.f32) {
+        if (v.table) return nullptr;
+        return v.mesh ? pick_tally<float, true, false>(v.tally) : pick_tally<float, false, false>(v.tally);
+    }
+    if (v.table) return v.mesh ? pick_tally<double, true, true>(v.tally) : pick_tally<double, false, true>(v.tally);
+    return v.mesh ? pick_tally<double, true, false>(v.tally) : pick_tally<double, false, false>(v.tally);
+}
+
+size_t walk_lds_bytes(const Variant& v, int n_media, int n_layers, int n_tris, int n_nodes)
+{
+    if (v.mesh) n_layers = 0; else { n_tris = 0; n_nodes = 0; }
+    return v.f32 ? LdsLayout<float>(n_media, n_layers, n_tris, n_nodes).total
+                 : LdsLayout<double>(n_media, n_layers, n_tris, n_nodes).total;
+}
+
+int walk_max_blocks_per_cu(const Variant& v, int threads, size_t lds_bytes)
+{
+    WalkFn fn = pick(v);
+    if (!fn) return 0;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(fn), threads, lds_bytes) != hipSuccess)
+        return 0;
+    return nb;
+}
+
+hipError_t launch_walk(const WalkParams& Pin, const Variant& v, const LaunchCfg& cfg, hipStream_t s)
+{
+    WalkFn fn = pick(v);
+    if (!fn) return hipErrorInvalidValue;
+    WalkParams P = Pin;
+    if (v.mesh) P.n_layers = 0; else { P.n_tris = 0; P.n_nodes = 0; }
+    if (cfg.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(fn, dim3(cfg.blocks), dim3(cfg.threads), cfg.lds_bytes, s, P);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// query kernels: the same __device__ functions, one lane per query (f64)
+// ---------------------------------------------------------------------------
+__global__ void k_intersect_rays(const TriD<double>* tris, const NodeD<double>* nodes, int n_tris, int n_nodes,
+                                 const double* o, const double* d, const double* tmax, size_t n, int use_bvh,
+                                 int32_t* prim, double* t)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double oo[3] = {o[3 * i], o[3 * i + 1], o[3 * i + 2]}, dd[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+    double tm = tmax ? tmax[i] : __builtin_huge_val();
+    int pi; double tt;
+    if (use_bvh) nearest_bvh(tris, nodes, n_nodes, oo, dd, tm, pi, tt);
+    else nearest_brute(tris, n_tris, oo, dd, tm, pi, tt);
+    prim[i] = pi; t[i] = tt;
+}
+
+__global__ void k_triangle_intersect(const double* o, const double* d, const double* tris, size_t n, double* t)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // derive the PreComputedTriangle fields exactly as the host does
+    // (S/primitives.py:105-111), without fused multiply-adds
+    const double* a = tris + 9 * i; const double* b = a + 3; const double* c = a + 6;
+    TriD<double> T;
+    {
+#pragma clang fp contract(off)
+        for (int k = 0; k < 3; k++) { T.a[k] = a[k]; T.ab[k] = b[k] - a[k]; T.ac[k] = c[k] - a[k]; }
+        double nn[3];
+        nn[0] = T.ab[1] * T.ac[2] - T.ab[2] * T.ac[1];
+        nn[1] = T.ab[2] * T.ac[0] - T.ab[0] * T.ac[2];
+        nn[2] = T.ab[0] * T.ac[1] - T.ab[1] * T.ac[0];
+        double l = ::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+        for (int k = 0; k < 3; k++) T.n[k] = nn[k] / l;
+    }
+    T.med_front = T.med_back = -1;
+    double oo[3] = {o[3 * i], o[3 * i + 1], o[3 * i + 2]}, dd[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+    t[i] = tri_hit(oo, dd, &T);
+}
+
+__global__ void k_intersect_bounds(const double* o, const double* d, const double* tmax, const double* boxes,
+                                   size_t n, int32_t* hit)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double oo[3] = {o[3 * i], o[3 * i + 1], o[3 * i + 2]};
+    double inv[3] = {1.0 / d[3 * i], 1.0 / d[3 * i + 1], 1.0 / d[3 * i + 2]};
+    double lo[3] = {boxes[6 * i], boxes[6 * i + 1], boxes[6 * i + 2]};
+    double hi[3] = {boxes[6 * i + 3], boxes[6 * i + 4], boxes[6 * i + 5]};
+    hit[i] = box_hit(lo, hi, oo, inv, tmax ? tmax[i] : __builtin_huge_val()) ? 1 : 0;
+}
+
+__global__ void k_eval(int fn, const double* in, size_t n, double* out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    switch (fn) {
+    case LT_FN_HG_PDF: out[i] = hg_pdf(in[2 * i], in[2 * i + 1]); break;
+    case LT_FN_HG_SAMPLE: {
+        double g = in[2 * i + 1];
+        out[i] = hg_sample(in[2 * i], g, 1.0 - g * g, 1.0 + g * g, 1.0 / (2.0 * g));
+    } break;
+    case LT_FN_ONB: {
+        double nn[3] = {in[3 * i], in[3 * i + 1], in[3 * i + 2]}, v2[3], v3[3];
+        onb(nn, v2, v3);
+        for (int k = 0; k < 3; k++) { out[6 * i + k] = v2[k]; out[6 * i + 3 + k] = v3[k]; }
+    } break;
+    case LT_FN_DISK: { double dd[2]; disk(in[2 * i], in[2 * i + 1], dd); out[2 * i] = dd[0]; out[2 * i + 1] = dd[1]; } break;
+    case LT_FN_COSINE_HEMI: {
+        double nn[3] = {in[8 * i], in[8 * i + 1], in[8 * i + 2]}, wi[3] = {in[8 * i + 3], in[8 * i + 4], in[8 * i + 5]}, o4[4];
+        cosine_hemi(nn, wi, in[8 * i + 6], in[8 * i + 7], o4);
+        for (int k = 0; k < 4; k++) out[4 * i + k] = o4[k];
+    } break;
+    case LT_FN_REFLECT: {
+        double v[3] = {in[6 * i], in[6 * i + 1], in[6 * i + 2]}, nn[3] = {in[6 * i + 3], in[6 * i + 4], in[6 * i + 5]}, r[3];
+        reflect(v, nn, r);
+        for (int k = 0; k < 3; k++) out[3 * i + k] = r[k];
+    } break;
+    case LT_FN_BOUNDARY: {
+        double dd[3] = {in[8 * i], in[8 * i + 1], in[8 * i + 2]}, nf[3] = {in[8 * i + 3], in[8 * i + 4], in[8 * i + 5]}, ct, refr[3];
+        out[5 * i] = boundary(dd, nf, in[8 * i + 6], in[8 * i + 7], &ct, refr);
+        out[5 * i + 1] = ct; out[5 * i + 2] = refr[0]; out[5 * i + 3] = refr[1]; out[5 * i + 4] = refr[2];
+    } break;
+    case LT_FN_SPIN: {
+        double u[3] = {in[5 * i], in[5 * i + 1], in[5 * i + 2]};
+        spin(u, in[5 * i + 3], in[5 * i + 4]);
+        for (int k = 0; k < 3; k++) out[3 * i + k] = u[k];
+    } break;
+    }
+}
+
+__global__ void k_rng_raw(unsigned long long seed, unsigned long long photon_id, unsigned count, uint32_t* out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    rocrand_state_xorwow st;
+    rocrand_init(mix_seed(seed, photon_id), 0ull, 0ull, &st);
+    for (unsigned i = 0; i < count; i++) out[i] = rocrand(&st);
+}
+
+__global__ void k_grid_to_f64(const void* grid, int tally, size_t n, double* out)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (tally == LT_TALLY_F32) out[i] = (double)reinterpret_cast<const float*>(grid)[i];
+        else if (tally == LT_TALLY_F64) out[i] = reinterpret_cast<const double*>(grid)[i];
+        else out[i] = (double)reinterpret_cast<const unsigned long long*>(grid)[i] * (1.0 / LT_FX_SCALE);
+    }
+}
+
+static inline unsigned nblk(size_t n, unsigned t) { return (unsigned)((n + t - 1) / t); }
+
+hipError_t launch_intersect_rays(const void* tris, const void* nodes, int n_tris, int n_nodes, const double* o,
+                                 const double* d, const double* tmax, size_t n, int use_bvh, int32_t* prim,
+                                 double* t, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_intersect_rays, dim3(nblk(n, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const TriD<double>*>(tris), reinterpret_cast<const NodeD<double>*>(nodes),
+                       n_tris, n_nodes, o, d, tmax, n, use_bvh, prim, t);
+    return hipGetLastError();
+}
+hipError_t launch_triangle_intersect(const double* o, const double* d, const double* tris, size_t n, double* t,
+                                     hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_triangle_intersect, dim3(nblk(n, 256)), dim3(256), 0, s, o, d, tris, n, t);
+    return hipGetLastError();
+}
+hipError_t launch_intersect_bounds(const double* o, const double* d, const double* tmax, const double* boxes,
+                                   size_t n, int32_t* hit, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_intersect_bounds, dim3(nblk(n, 256)), dim3(256), 0, s, o, d, tmax, boxes, n, hit);
+    return hipGetLastError();
+}
+hipError_t launch_eval(int fn, const double* in, size_t n, double* out, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_eval, dim3(nblk(n, 256)), dim3(256), 0, s, fn, in, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_rng_raw(unsigned long long seed, unsigned long long photon_id, unsigned count, uint32_t* out,
+                          hipStream_t s)
+{
+    hipLaunchKernelGGL(k_rng_raw, dim3(1), dim3(64), 0, s, seed, photon_id, count, out);
+    return hipGetLastError();
+}
+hipError_t launch_grid_to_f64(const void* grid, int tally, size_t n, double* out, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_grid_to_f64, dim3(2048), dim3(256), 0, s, grid, tally, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace ltk
