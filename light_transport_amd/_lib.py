@@ -159,7 +159,7 @@ class Context:
         self._ck(lib().lt_set_mesh(self._h, _dp(v), _ip(mf), _ip(mb), C.c_int(v.shape[0]), arr, C.c_int(n)),
                  "lt_set_mesh")
 
-    def set_grid(self, shape, origin, voxel, dtype="f32"):
+    def set_grid(self, shape, origin, voxel, dtype="f64"):
         nx, ny, nz = (int(s) for s in shape)
         o = (C.c_double * 3)(*map(float, origin))
         vx = (C.c_double * 3)(*map(float, voxel))

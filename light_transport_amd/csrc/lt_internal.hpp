@@ -9,8 +9,7 @@
 namespace ltk {
 
 // Per-medium constants in walk precision R.  Derived values are computed on the
-// host in double, one IEEE operation each, then narrowed -- the same recipe as
-// the oracle, so both sides start from identical bits.
+// host in double, one IEEE operation each, then narrowed.
 template <typename R>
 struct MedD {
     R mu_t, inv_mu_t, absorb, g;

@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ from the REFERENCE's own
+function bodies.  Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+How the reference is executed.  Every reference module does ``import numba`` and
+Numba is not installed in this image (and cannot be: no network).  The reference's
+jitted functions are ordinary Python/NumPy underneath their decorators, so this
+script puts a small identity-decorator module named ``numba`` in a temp directory
+on sys.path (njit/jit return the function unchanged, jitclass returns the class,
+prange = range, type tokens are inert) and imports the reference from
+/root/reference.  What is captured is therefore the output of the reference's
+function bodies run by CPython + NumPy float64 -- no JIT.  The shipped
+``__pycache__/*.pyc`` files are NOT loaded (sys.pycache_prefix is redirected) and
+nothing is written under /root/reference.
+
+Only numbers are stored: inputs and the reference's outputs (.npz).  No reference
+source text is copied.  Fixture ids follow SURVEY.md section 8(c).
+"""
+import os
+import sys
+import tempfile
+import textwrap
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(OUT))
+
+STUB = textwrap.dedent('''
+    """Identity stand-in for the numba surface the reference touches (test tooling)."""
+    import sys, types
+
+    def _decorator(*args, **kwargs):
+        if len(args) == 1 and callable(args[0]) and not kwargs and not isinstance(args[0], _Tok):
+            return args[0]
+        return lambda f: f
+    njit = jit = _decorator
+    prange = range
+
+    class _Tok:
+        def __getitem__(self, k): return self
+        def __call__(self, *a, **k): return self
+        def define(self, *a, **k): return None
+    float64 = float32 = intp = uintp = int8 = int64 = boolean = _Tok()
+    def optional(x): return _Tok()
+    def deferred_type(): return _Tok()
+    def typeof(x): return _Tok()
+
+    types_mod = types.ModuleType("numba.types")
+    types_mod.ListType = lambda x: _Tok()
+    types_mod.Array = lambda **k: _Tok()
+    sys.modules["numba.types"] = types_mod
+    types = types_mod
+
+    class _CT:
+        instance_type = _Tok()
+    def _jitclass(spec=None):
+        def wrap(cls):
+            cls.class_type = _CT()
+            return cls
+        return wrap
+    experimental = types_mod.__class__("numba.experimental")
+    experimental.jitclass = _jitclass
+    sys.modules["numba.experimental"] = experimental
+
+    class _List(list):
+        @classmethod
+        def empty_list(cls, t): return cls()
+    typed = types_mod.__class__("numba.typed")
+    typed.List = _List
+    sys.modules["numba.typed"] = typed
+''')
+
+
+def import_reference():
+    tmp = tempfile.mkdtemp(prefix="lt_golden_")
+    os.makedirs(os.path.join(tmp, "numba"))
+    with open(os.path.join(tmp, "numba", "__init__.py"), "w") as f:
+        f.write(STUB)
+    sys.pycache_prefix = os.path.join(tmp, "pycache")  # neither read the shipped .pyc nor write into REF
+    sys.dont_write_bytecode = True
+    sys.path[:0] = [tmp, REF]
+    import importlib
+    base = "LightTransportSimulator.light_transport.src."
+    return {m: importlib.import_module(base + m) for m in
+            ("medium_samples", "intersects", "primitives", "utils", "brdf", "scene", "rays", "material", "bvh_new",
+             "constants")}
+
+
+def h4(v, w):
+    return np.ascontiguousarray(np.append(np.asarray(v, dtype=np.float64), w))
+
+
+def main():
+    R = import_reference()
+    sys.path.insert(0, REPO)
+    rs = np.random.RandomState(20240925)
+    mat = R["material"].Material(R["material"].Color(np.zeros(3), np.ones(3), np.ones(3)), 1.0, 0.1, 1.5)
+    PCT = R["primitives"].PreComputedTriangle
+
+    # ---- G1: henyey_greenstein (medium_samples.py:14-16)
+    cos_t = np.linspace(-1.0, 1.0, 201)
+    gs = np.array([-0.9, -0.5, -0.1, 0.0, 0.1, 0.5, 0.75, 0.9, 0.99])
+    hg = np.stack([R["medium_samples"].henyey_greenstein(cos_t, g) for g in gs])
+    np.savez(os.path.join(OUT, "g1_henyey_greenstein.npz"), cos_theta=cos_t, g=gs, value=hg)
+
+    # ---- G2: triangle_intersect (intersects.py:46-104), 10^4 random pairs + edge cases
+    n = 10000
+    tris = rs.uniform(-2, 2, size=(n, 3, 3))
+    org = rs.uniform(-3, 3, size=(n, 3))
+    tgt = tris.mean(axis=1) + rs.normal(0, 0.7, size=(n, 3))       # aim near the triangle: ~half hit
+    dirs = tgt - org
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    k = 400   # rays parallel to the plane, rays starting on the plane, rays through a vertex / an edge
+    e1, e2 = tris[:k, 1] - tris[:k, 0], tris[:k, 2] - tris[:k, 0]
+    dirs[:100] = e1[:100] / np.linalg.norm(e1[:100], axis=1, keepdims=True)
+    org[100:200] = tris[100:200, 0] + 0.25 * e1[100:200] + 0.25 * e2[100:200]
+    d = tris[200:300, 1] - org[200:300]; dirs[200:300] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    d = (tris[300:400, 0] + 0.5 * e1[300:400]) - org[300:400]; dirs[300:400] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    t_ref = np.full(n, np.nan)
+    for i in range(n):
+        tri = PCT(h4(tris[i, 0], 1), h4(tris[i, 1], 1), h4(tris[i, 2], 1), mat)
+        t = R["intersects"].triangle_intersect(h4(org[i], 1), h4(dirs[i], 0), tri)
+        if t is not None:
+            t_ref[i] = t
+    np.savez(os.path.join(OUT, "g2_triangle_intersect.npz"), tris=tris, origins=org, dirs=dirs, t=t_ref)
+
+    # ---- G3: intersect_bounds (intersects.py:179-196) incl. axis-parallel rays (inv_dir = +-inf)
+    lo = rs.uniform(-2, 1, size=(n, 3)); hi = lo + rs.uniform(0.05, 2, size=(n, 3))
+    org = rs.uniform(-3, 3, size=(n, 3))
+    dirs = rs.normal(size=(n, 3))
+    aim = lo + rs.rand(n, 3) * (hi - lo) - org                     # 60 % aimed at a point inside the box
+    dirs[4000:] = aim[4000:]
+    dirs[:1500, 0] = 0.0; dirs[500:2000, 1] = 0.0; dirs[1000:1500, 2] = 1.0   # 1, 2 zero components
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    org[2000:2300] = 0.5 * (lo[2000:2300] + hi[2000:2300])                     # origin inside the box
+    org[2300:2600, 0] = lo[2300:2600, 0]; dirs[2300:2600, 0] = 0.0           # sliding along a face: 0 * inf = NaN lanes
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    tmax = np.where(rs.rand(n) < 0.5, np.inf, rs.uniform(0.1, 6.0, size=n))
+    hit = np.zeros(n, dtype=np.int32)
+    Ray = R["rays"].Ray
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for i in range(n):
+            ray = Ray(h4(org[i], 1), h4(dirs[i], 0)); ray.tmax = tmax[i]
+            box = R["primitives"].AABB(h4(lo[i], 1), h4(hi[i], 1))
+            hit[i] = bool(R["intersects"].intersect_bounds(box, ray, 1 / ray.direction))
+    np.savez(os.path.join(OUT, "g3_intersect_bounds.npz"), lo=lo, hi=hi, origins=org, dirs=dirs, tmax=tmax, hit=hit)
+
+    # ---- G4: nearest hit on the hand-restated Cornell box + cone: brute force with the
+    # reference's triangle_intersect and its predicate EPSILON < t < min_distance (bvh_new.py:438)
+    from light_transport_amd.src import cornell_box as cb, constants as K
+    scene = (cb.get_cornell_box(7.5, K.GLASS_MAT, K.GLASS_MAT, K.GLASS_MAT) + cb.get_front_wall(7.5, K.GLASS_MAT)
+             + cb.get_light_quad(7.5, K.GLASS_MAT) + cb.get_cone(K.GLASS_MAT))
+    verts = np.stack([t.vertices3() for t in scene])
+    ref_tris = [PCT(h4(v[0], 1), h4(v[1], 1), h4(v[2], 1), mat) for v in verts]
+    nr = 4000
+    org = rs.uniform(-7.0, 7.0, size=(nr, 3))
+    dirs = rs.normal(size=(nr, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    tmax = np.where(rs.rand(nr) < 0.7, np.inf, rs.uniform(0.5, 10.0, size=nr))
+    EPS = R["constants"].EPSILON
+    prim = -np.ones(nr, dtype=np.int32); tt = np.full(nr, np.inf)
+    for i in range(nr):
+        best = tmax[i]
+        for j, tri in enumerate(ref_tris):
+            t = R["intersects"].triangle_intersect(h4(org[i], 1), h4(dirs[i], 0), tri)
+            if t is not None and EPS < t < best:
+                best, prim[i] = t, j
+        if prim[i] >= 0:
+            tt[i] = best
+    # the reference's own builder on the same triangles: only its invariants are pinned
+    B = R["bvh_new"]
+    boxes = [B.BoundedBox(t, i) for i, t in enumerate(ref_tris)]
+    root, boxes, ordered, total = B.build_bvh(ref_tris, boxes, 0, len(boxes), [], 0)
+    lin, _ = B.flatten_bvh([B.LinearBVHNode() for _ in range(total)], root, 0)
+    np.savez(os.path.join(OUT, "g4_scene_nearest_hit.npz"), verts=verts, origins=org, dirs=dirs, tmax=tmax,
+             prim=prim, t=tt, ref_total_nodes=np.int64(total),
+             ref_leaf_prim_sum=np.int64(sum(nd.n_primitives for nd in lin)))
+
+    # ---- G5: sampling frames (utils.py:72-161, brdf.py:8-9)
+    m = 2000
+    nrm = rs.normal(size=(m, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm[:6] = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]], dtype=np.float64)
+    wi = rs.normal(size=(m, 3)); wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    u = rs.rand(m, 2); u[:4] = [[0.5, 0.5], [0.0, 0.0], [0.5, 0.25], [0.25, 0.5]]
+    onb = np.zeros((m, 6)); dsk = np.zeros((m, 2)); hemi = np.zeros((m, 4)); refl = np.zeros((m, 3))
+    U = R["utils"]
+    for i in range(m):
+        v2, v3 = U.create_orthonormal_system(h4(nrm[i], 0))
+        onb[i, :3], onb[i, 3:] = v2, v3
+        dsk[i] = U.concentric_sample_disk(u[i])
+        dd, pdf = U.cosine_weighted_hemisphere_sampling(h4(nrm[i], 0), h4(wi[i], 0), [u[i, 0], u[i, 1]])
+        hemi[i, :3], hemi[i, 3] = dd[:3], pdf
+        refl[i] = R["brdf"].get_reflected_direction(h4(wi[i], 0), h4(nrm[i], 0))[:3]
+    np.savez(os.path.join(OUT, "g5_sampling.npz"), normals=nrm, incoming=wi, u=u, onb=onb, disk=dsk, cosine_hemi=hemi,
+             reflected=refl)
+
+    # ---- G6: PreComputedTriangle / AABB derived fields (primitives.py:75-80, 99-112)
+    tv = rs.uniform(-5, 5, size=(500, 3, 3))
+    f = np.zeros((500, 13))
+    for i in range(500):
+        t = PCT(h4(tv[i, 0], 1), h4(tv[i, 1], 1), h4(tv[i, 2], 1), mat)
+        f[i] = np.concatenate([t.centroid[:3], t.edge_1[:3], t.edge_2[:3], t.normal[:3], [t.num]])
+    bb = R["primitives"].AABB(np.array([-1.0, 2.0, 3.0]), np.array([4.0, 6.0, 5.0]))
+    np.savez(os.path.join(OUT, "g6_triangle_fields.npz"), tris=tv, fields=f, aabb_centroid=bb.centroid)
+
+    # ---- G7: Scene table RNG (scene.py:68-69) after np.random.seed(0)
+    np.random.seed(0)
+    sc = R["scene"].Scene(np.zeros(4), [], width=6, height=5, max_depth=4, f_distance=5, number_of_samples=3)
+    np.savez(os.path.join(OUT, "g7_scene_tables.npz"), shape=np.array(sc.rand_0.shape), rand_0=sc.rand_0,
+             rand_1=sc.rand_1, image_shape=np.array(sc.image.shape))
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""Transport problems used by the tests, described ONCE and applied both to the
+CPU oracle (oracle.OracleScene) and to the HIP path (Context.set_*), so both sides
+see identical inputs.  C1..C4 follow BASELINE.json's configs / SURVEY.md 8(d)."""
+import numpy as np
+
+from light_transport_amd.src import bvh_new as B
+from light_transport_amd.src import constants as K
+from light_transport_amd.src import cornell_box as cb
+from oracle import oracle as O
+
+
+class Problem:
+    def __init__(self, media, grid_shape, origin, voxel, layers=None, mesh=None, source=None, max_steps=1000000):
+        self.media, self.grid_shape, self.origin, self.voxel = media, grid_shape, origin, voxel
+        self.layers, self.mesh, self.max_steps = layers, mesh, max_steps
+        self.source = source or dict(type=0, pos=(0.0, 0.0, 0.0), dir=(0.0, 0.0, 1.0), extra=(0.0,) * 6, start_medium=0)
+
+    def oracle(self):
+        return O.OracleScene(self.media, self.grid_shape, self.origin, self.voxel, layers=self.layers, mesh=self.mesh,
+                             source=self.source, max_steps=self.max_steps)
+
+    def apply(self, ctx, dtype="f64"):
+        ctx.set_media(self.media)
+        if self.layers is not None:
+            ctx.set_layers(self.layers["z_bounds"], self.layers["medium_idx"], self.layers.get("n_above", 1.0),
+                           self.layers.get("n_below", 1.0))
+        else:
+            ctx.set_mesh(self.mesh["verts"], self.mesh["med_front"], self.mesh["med_back"], self.mesh["nodes"])
+        ctx.set_grid(self.grid_shape, self.origin, self.voxel, dtype)
+        s = self.source
+        ctx.set_source(s.get("type", 0), s["pos"], s["dir"], s.get("extra"), s.get("start_medium", 0))
+        ctx.set_max_steps(self.max_steps)
+        return ctx
+
+
+def slab(n=64, voxel=0.4, media=((0.1, 10.0, 0.9, 1.0),), thickness=np.inf, n_above=1.0, n_below=1.0, **kw):
+    """C1 (n=64, voxel 0.4) / C2 (n=256, voxel 0.1): homogeneous semi-infinite slab, pencil beam."""
+    half = n * voxel / 2
+    return Problem(list(media), (n, n, n), (-half, -half, 0.0), (voxel,) * 3,
+                   layers=dict(z_bounds=[0.0, thickness], medium_idx=[0], n_above=n_above, n_below=n_below), **kw)
+
+
+def two_layer(n=64, voxel=0.2, **kw):
+    """C3: epidermis 0-0.1 mm over dermis, ambient n = 1 (values of SURVEY.md 8(d))."""
+    half = n * voxel / 2
+    media = [(0.43, 10.7, 0.79, 1.5), (0.27, 18.7, 0.82, 1.4)]
+    return Problem(media, (n, n, n), (-half, -half, 0.0), (voxel,) * 3,
+                   layers=dict(z_bounds=[0.0, 0.1, np.inf], medium_idx=[0, 1], n_above=1.0, n_below=1.0), **kw)
+
+
+def cornell_scene(split_method=1):
+    """The 30-triangle Cornell cavity + cone of config 4, in BVH order, with media labels."""
+    dim = 7.5
+    walls = (cb.get_cornell_box(dim, K.GLASS_MAT, K.GLASS_MAT, K.GLASS_MAT) + cb.get_front_wall(dim, K.GLASS_MAT)
+             + cb.get_light_quad(dim, K.GLASS_MAT))
+    cone = cb.get_cone(K.GLASS_MAT)
+    for t in walls:   # normals point into the cavity: front = cavity medium, back = exterior
+        t.med_front, t.med_back = 0, -1
+    for t in cone:    # normals point out of the cone: front = cavity medium, back = cone medium
+        t.med_front, t.med_back = 0, 1
+    ordered, linear = B.build_linear_bvh(walls + cone, split_method)
+    return ordered, linear
+
+
+def cornell(n=64, **kw):
+    """C4: C1's medium fills the cube, a cone of a second medium sits in it, cosine source on the ceiling quad."""
+    dim = 7.5
+    ordered, linear = cornell_scene()
+    mesh = dict(verts=B.triangles_array(ordered), med_front=np.array([t.med_front for t in ordered], np.int32),
+                med_back=np.array([t.med_back for t in ordered], np.int32), nodes=B.linear_bvh_arrays(linear))
+    media = [(0.1, 10.0, 0.9, 1.0), (1.0, 5.0, 0.8, 1.5)]
+    src = dict(type=1, pos=(-1.0, dim, -1.0), dir=(0.0, -1.0, 0.0), extra=(2.0, 0.0, 0.0, 0.0, 0.0, 2.0), start_medium=0)
+    voxel = 2 * dim / n
+    return Problem(media, (n, n, n), (-dim, -dim, -dim), (voxel,) * 3, mesh=mesh, source=src, **kw)
+
+
+def assert_grid_close(g, go, rtol=1e-9, atol=1e-12, max_bad=0):
+    d = np.abs(g - go)
+    bad = int((d > atol + rtol * np.abs(go)).sum())
+    assert bad <= max_bad, "%d voxels outside |d| <= %g + %g*E (max abs %g)" % (bad, atol, rtol, d.max())

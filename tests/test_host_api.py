@@ -1,0 +1,162 @@
+"""CPU suite: host-side mirror of the reference API, and the C-ABI library's
+surface (loads, exports every symbol of include/lt.h, fails loudly without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import light_transport_amd as lt
+from light_transport_amd import _lib
+from light_transport_amd.src import bvh_new as B
+from light_transport_amd.src import constants as K
+from light_transport_amd.src import cornell_box as cb
+from light_transport_amd.src import photon_tracing as PT
+from light_transport_amd.src import primitives as P
+from light_transport_amd.src import scene as SC
+from light_transport_amd.src.stl4py import partition
+from tests import scenes as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "lt.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lt_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_header_symbol():
+    assert os.path.exists(lt.LIB_PATH), "liblt_hip.so not built: run __graft_entry__.build()"
+    L = ctypes.CDLL(lt.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "missing export " + n
+    assert sorted(_lib.SYMBOLS) == names
+    assert L.lt_abi_version() == 1
+
+
+def test_no_cpu_fallback_create_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the failure path is exercised on CPU-only hosts")
+    with pytest.raises(lt.LtError) as e:
+        lt.Context(0)
+    assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
+    with pytest.raises(lt.LtError):
+        PT.trace_photons(PT.LayeredSlab([PT.OpticalMedium(0.1, 10, 0.9)], [np.inf]), None, None, 10,
+                         grid=PT.VoxelGrid((4, 4, 4), (0, 0, 0), 1.0), source=PT.PencilBeam((0, 0, 0), (0, 0, 1)))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "light_transport_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dp, f)).read()
+                for pat in (r"import\s+oracle", r"from\s+oracle", r"oracle[/.]", r"liblt_oracle", r"\blto_"):
+                    assert not re.search(pat, txt), "product file reaches into oracle/: %s (%s)" % (os.path.join(dp, f), pat)
+
+
+def test_precomputed_triangle_matches_reference_fields(golden_dir):
+    g6 = np.load(os.path.join(golden_dir, "g6_triangle_fields.npz"))
+    for i in range(0, 500, 7):
+        v = g6["tris"][i]
+        t = P.PreComputedTriangle(np.append(v[0], 1.0), np.append(v[1], 1.0), np.append(v[2], 1.0), K.GLASS_MAT)
+        got = np.concatenate([t.centroid[:3], t.edge_1[:3], t.edge_2[:3], t.normal[:3], [t.num]])
+        np.testing.assert_allclose(got, g6["fields"][i], rtol=1e-13, atol=1e-12)
+        assert t.vertex_1.shape == (4,) and t.vertex_1[3] == 1.0 and t.normal[3] == 0.0
+        assert t.vertex_1.flags["C_CONTIGUOUS"]
+    box = P.AABB(np.array([-1.0, 2.0, 3.0]), np.array([4.0, 6.0, 5.0]))
+    np.testing.assert_array_equal(box.centroid, g6["aabb_centroid"])
+
+
+def test_scene_table_rng_matches_reference(golden_dir):
+    g7 = np.load(os.path.join(golden_dir, "g7_scene_tables.npz"))
+    np.random.seed(0)
+    sc = SC.Scene(np.zeros(4), [], width=6, height=5, max_depth=4, f_distance=5, number_of_samples=3)
+    assert tuple(g7["shape"]) == sc.rand_0.shape == (5, 6, 3, 4)
+    np.testing.assert_array_equal(sc.rand_0, g7["rand_0"])   # legacy MT19937 stream, same draw order
+    np.testing.assert_array_equal(sc.rand_1, g7["rand_1"])
+    assert sc.image.shape == tuple(g7["image_shape"])
+    tab = PT.uniform_table(7, 5, seed=0)
+    assert tab.shape == (7, 5, 4) and tab.min() >= 0 and tab.max() < 1
+    np.testing.assert_array_equal(tab.ravel()[:4], np.random.RandomState(0).rand(4))
+
+
+def test_partition():
+    rs = np.random.RandomState(1)
+    for _ in range(50):
+        n = rs.randint(0, 30)
+        a = list(rs.randint(0, 10, size=n))
+        lo, hi = sorted(rs.randint(0, n + 1, size=2)) if n else (0, 0)
+        b = list(a)
+        k = partition(b, lambda x: x < 5, first=lo, last=hi)
+        assert sorted(b[lo:hi]) == sorted(a[lo:hi]) and b[:lo] == a[:lo] and b[hi:] == a[hi:]
+        assert all(x < 5 for x in b[lo:k]) and all(x >= 5 for x in b[k:hi])
+
+
+def check_tree(linear, n_prims):
+    seen = np.zeros(n_prims, int)
+
+    def walk(i, depth):
+        nd = linear[i]
+        if nd.n_primitives > 0:
+            seen[nd.primitives_offset:nd.primitives_offset + nd.n_primitives] += 1
+            return i + 1, depth
+        nxt, d0 = walk(i + 1, depth + 1)
+        assert nd.second_child_offset == nxt          # B1 fixed: FIRST index of the right subtree
+        assert nd.axis in (0, 1, 2)
+        end, d1 = walk(nd.second_child_offset, depth + 1)
+        return end, max(d0, d1)
+    end, depth = walk(0, 0)
+    assert end == len(linear) and np.all(seen == 1)
+    return depth
+
+
+@pytest.mark.parametrize("split_method", [0, 1])
+def test_build_and_flatten_bvh(split_method):
+    dim = 7.5
+    prims = (cb.get_cornell_box(dim, K.GLASS_MAT, K.GLASS_MAT, K.GLASS_MAT) + cb.get_front_wall(dim, K.GLASS_MAT)
+             + cb.get_light_quad(dim, K.GLASS_MAT) + cb.get_cone(K.GLASS_MAT))
+    assert len(prims) == 30 and len(cb.get_cone(K.GLASS_MAT)) == 10   # LTS.ipynb cell 11 -> 10
+    boxes = [B.BoundedBox(p, i) for i, p in enumerate(prims)]
+    root, boxes, ordered, total = B.build_bvh(prims, boxes, 0, len(boxes), [], 0, split_method)
+    linear, used = B.flatten_bvh([B.LinearBVHNode() for _ in range(total)], root, 0)
+    assert used == total == len(linear)
+    assert sum(n.n_primitives for n in linear) == len(prims)          # LTS.ipynb cell 23
+    assert sorted(map(id, ordered)) == sorted(map(id, prims))
+    depth = check_tree(linear, len(prims))
+    assert depth < 31
+    # every node bounds its primitives; children are spatially separated on the split axis (B2 fixed)
+    for nd in linear:
+        if nd.n_primitives > 0:
+            for t in ordered[nd.primitives_offset:nd.primitives_offset + nd.n_primitives]:
+                for v in (t.vertex_1, t.vertex_2, t.vertex_3):
+                    assert np.all(v[:3] >= nd.bounds.min_point[:3] - 1e-12) and np.all(v[:3] <= nd.bounds.max_point[:3] + 1e-12)
+    arr = B.linear_bvh_arrays(linear)
+    assert arr["lo"].shape == (total, 3) and (arr["n_prims"] > 0).sum() >= 10
+
+
+def test_bvh_on_many_random_triangles():
+    rs = np.random.RandomState(3)
+    prims = [P.PreComputedTriangle(c + rs.normal(0, 0.2, 3), c + rs.normal(0, 0.2, 3), c + rs.normal(0, 0.2, 3), K.GLASS_MAT)
+             for c in rs.uniform(-5, 5, size=(300, 3))]
+    for sm in (0, 1):
+        ordered, linear = B.build_linear_bvh(prims, sm)
+        check_tree(linear, 300)
+
+
+def test_photon_tracing_objects():
+    slab = PT.LayeredSlab([PT.OpticalMedium(0.43, 10.7, 0.79, 1.5), PT.OpticalMedium(0.27, 18.7, 0.82, 1.4)], [0.1, np.inf])
+    np.testing.assert_array_equal(slab.z_bounds, [0.0, 0.1, np.inf])
+    g = PT.VoxelGrid((8, 9, 10), (0, 0, 0), 0.5)
+    assert g.voxel == (0.5, 0.5, 0.5) and abs(g.voxel_volume - 0.125) < 1e-15
+    f = PT.fluence(np.ones((2, 2, 2)), 0.1, 0.125, 100)
+    np.testing.assert_allclose(f, 1.0 / (0.1 * 0.125 * 100))
+    with pytest.raises(ValueError):
+        PT.LayeredSlab([], [])
+    prob = S.cornell(16)
+    assert prob.mesh["verts"].shape == (30, 3, 3) and set(prob.mesh["med_back"]) == {-1, 1}

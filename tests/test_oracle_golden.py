@@ -1,0 +1,245 @@
+"""CPU suite (no GPU): pins the oracle.
+
+Part 1 -- the reference functions that exist: the oracle's C restatement must
+reproduce the golden vectors captured from the reference's own function bodies
+(tests/golden/make_golden.py).  Bit-exact where the reference does the same IEEE
+operations in the same order; a stated ulp-level tolerance elsewhere.
+
+Part 2 -- the volumetric walk, which the reference does not contain (PARITY
+UNPINNED against it): analytic known answers (SURVEY.md 8(c) i-vii).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import scenes as S
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ------------------------------------------------------------------ part 1
+def test_g1_henyey_greenstein(golden_dir):
+    g1 = load(golden_dir, "g1_henyey_greenstein.npz")
+    for gi, g in enumerate(g1["g"]):
+        inp = np.stack([g1["cos_theta"], np.full_like(g1["cos_theta"], g)], axis=1)
+        out = O.eval_fn("HG_PDF", inp)[:, 0]
+        np.testing.assert_allclose(out, g1["value"][gi], rtol=4e-16, atol=0)
+    # sign convention (pbrt): g > 0 peaks at cos = -1
+    assert O.eval_fn("HG_PDF", [[-1.0, 0.9]])[0, 0] > 1000 * O.eval_fn("HG_PDF", [[1.0, 0.9]])[0, 0]
+
+
+def test_g1_sampler_density_is_reference_pdf():
+    """pdf of the deflection-cosine sampler == henyey_greenstein(-cos, g) (G1's role for the sampler)."""
+    for g in (-0.7, 0.3, 0.9):
+        xi = (np.arange(400000) + 0.5) / 400000
+        c = O.eval_fn("HG_SAMPLE", np.stack([xi, np.full_like(xi, g)], axis=1))[:, 0]
+        hist, edges = np.histogram(c, bins=50, range=(-1, 1), density=True)
+        # bin-averaged reference value (azimuth integrated: x 2 pi), 64 sub-points per bin
+        sub = (edges[:-1, None] + (edges[1:, None] - edges[:-1, None]) * (np.arange(64) + 0.5) / 64).ravel()
+        ref = 2 * np.pi * O.eval_fn("HG_PDF", np.stack([-sub, np.full_like(sub, g)], axis=1))[:, 0]
+        np.testing.assert_allclose(hist, ref.reshape(50, 64).mean(axis=1), rtol=2e-3, atol=1e-4)
+        assert abs(c.mean() - g) < 1e-4
+
+
+def barycentric_margin(origins, dirs, tris):
+    """Distance of the ray/plane hit from the nearest triangle edge, in barycentric
+    units (NumPy float64).  Where it is below ~1e-10 the reference's own accept /
+    reject decision hinges on the summation order inside np.dot (BLAS), so such
+    knife-edge rays (aimed exactly at a vertex or an edge) are compared on t only."""
+    a, ab, ac = tris[:, 0], tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]
+    p = np.cross(dirs, ac)
+    det = np.einsum("ij,ij->i", ab, p)
+    with np.errstate(all="ignore"):
+        tv = origins - a
+        u = np.einsum("ij,ij->i", tv, p) / det
+        q = np.cross(tv, ab)
+        v = np.einsum("ij,ij->i", dirs, q) / det
+        t = np.einsum("ij,ij->i", ac, q) / det
+    with np.errstate(all="ignore"):
+        m = np.minimum(np.minimum(np.abs(u), np.abs(v)), np.minimum(np.abs(1 - u - v), np.abs(1 - u)))
+        m = np.minimum(m, np.abs(t - 1e-7) * 1e3)
+    n = np.cross(ab, ac); n /= np.linalg.norm(n, axis=1, keepdims=True)
+    m = np.minimum(m, np.abs(np.abs(np.einsum("ij,ij->i", dirs, n)) - 1e-7) * 1e3)
+    return np.where(np.isfinite(m), m, 0.0)
+
+
+def check_triangle_hits(t, g2):
+    ref = g2["t"]
+    safe = barycentric_margin(g2["origins"], g2["dirs"], g2["tris"]) > 1e-10
+    assert safe.mean() > 0.95
+    assert np.array_equal(np.isnan(t)[safe], np.isnan(ref)[safe]), "hit/miss decisions differ from the reference"
+    both = ~np.isnan(t) & ~np.isnan(ref)
+    assert both.sum() > 2000 and np.isnan(ref).sum() > 2000
+    np.testing.assert_allclose(t[both], ref[both], rtol=1e-12, atol=0)
+
+
+def test_g2_triangle_intersect(golden_dir):
+    g2 = load(golden_dir, "g2_triangle_intersect.npz")
+    check_triangle_hits(O.triangle_intersect(g2["origins"], g2["dirs"], g2["tris"]), g2)
+
+
+def test_g3_intersect_bounds(golden_dir):
+    g3 = load(golden_dir, "g3_intersect_bounds.npz")
+    boxes = np.concatenate([g3["lo"], g3["hi"]], axis=1)
+    hit = O.intersect_bounds(g3["origins"], g3["dirs"], boxes, g3["tmax"])
+    np.testing.assert_array_equal(hit, g3["hit"])
+    assert 1000 < g3["hit"].sum() < 9000
+
+
+def test_g4_nearest_hit_bvh_and_brute(golden_dir):
+    g4 = load(golden_dir, "g4_scene_nearest_hit.npz")
+    ordered, linear = S.cornell_scene()
+    from light_transport_amd.src import bvh_new as B
+    verts = B.triangles_array(ordered)
+    # map BVH order back to the fixture's triangle order
+    key = {tuple(np.round(v.ravel(), 9)): i for i, v in enumerate(g4["verts"])}
+    back = np.array([key[tuple(np.round(v.ravel(), 9))] for v in verts])
+    sc = O.OracleScene([(0, 0, 0, 1)], (1, 1, 1), (0, 0, 0), (1, 1, 1),
+                       mesh=dict(verts=verts, med_front=-np.ones(len(verts), np.int32),
+                                 med_back=-np.ones(len(verts), np.int32), nodes=B.linear_bvh_arrays(linear)))
+    for use_bvh in (True, False):
+        prim, t = sc.intersect_rays(g4["origins"], g4["dirs"], g4["tmax"], use_bvh=use_bvh)
+        got = np.where(prim >= 0, back[np.maximum(prim, 0)], -1)
+        np.testing.assert_array_equal(got, g4["prim"])
+        np.testing.assert_allclose(t, g4["t"], rtol=1e-12, atol=0)  # np.dot's summation order is BLAS's
+    assert (g4["prim"] >= 0).mean() > 0.5
+    # invariants the reference's own notebook checks (LTS.ipynb cells 21-23)
+    assert int(g4["ref_leaf_prim_sum"]) == len(g4["verts"])
+
+
+def test_g5_sampling_frames(golden_dir):
+    g5 = load(golden_dir, "g5_sampling.npz")
+    np.testing.assert_array_equal(O.eval_fn("ONB", g5["normals"]), g5["onb"])
+    np.testing.assert_allclose(O.eval_fn("DISK", g5["u"]), g5["disk"], rtol=0, atol=2e-16)
+    hemi = O.eval_fn("COSINE_HEMI", np.concatenate([g5["normals"], g5["incoming"], g5["u"]], axis=1))
+    np.testing.assert_allclose(hemi, g5["cosine_hemi"], rtol=0, atol=5e-16)
+    refl = O.eval_fn("REFLECT", np.concatenate([g5["incoming"], g5["normals"]], axis=1))
+    np.testing.assert_allclose(refl, g5["reflected"], rtol=0, atol=1e-15)  # np.linalg.norm vs sqrt(sum)
+
+
+def test_g6_triangle_fields(golden_dir):
+    g6 = load(golden_dir, "g6_triangle_fields.npz")
+    f = O.triangle_fields(g6["tris"])
+    np.testing.assert_allclose(f[:, :12], g6["fields"][:, :12], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(f[:, 12], g6["fields"][:, 12], rtol=1e-13, atol=1e-12)  # a cancelling dot product
+
+
+# ------------------------------------------------------------------ part 2
+def test_xorwow_known_answer():
+    """Marsaglia's xorwow with rocRAND's seeding: seed 0 state is the published
+    initial state scrambled by the two prime multiples; stream is deterministic."""
+    a, b = O.rng_raw(0, 0, 8), O.rng_raw(0, 0, 8)
+    assert np.array_equal(a, b)
+    assert len(set(O.rng_raw(0, i, 1)[0] for i in range(1000))) == 1000  # distinct streams per photon
+    # statistical sanity of the uniforms
+    v = np.concatenate([O.rng_raw(5, i, 256) for i in range(400)]).astype(np.float64) / 2 ** 32
+    assert abs(v.mean() - 0.5) < 0.005 and abs(v.var() - 1 / 12) < 0.003
+
+
+def test_energy_conservation_all_geometries():
+    for prob, n in ((S.slab(), 3000), (S.two_layer(), 3000), (S.cornell(32), 1500),
+                    (S.slab(media=((10.0, 90.0, 0.75, 1.0),), thickness=0.02, n=8, voxel=0.0025), 3000)):
+        g, _, c = prob.oracle().run(n, seed=11)
+        assert abs(O.conservation_residual(c)) < 1e-11 * n
+        assert abs(g.sum() - c["w_absorbed"]) < 1e-9 * n
+        assert c["photons"] == n and c["steps"] > n
+
+
+def test_beer_lambert_pure_absorber():
+    mu_a, vz, nz = 2.0, 0.05, 40
+    prob = S.Problem([(mu_a, 0.0, 0.0, 1.0)], (1, 1, nz), (-1.0, -1.0, 0.0), (2.0, 2.0, vz),
+                     layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))
+    n = 200000
+    g, _, c = prob.oracle().run(n, seed=3, threads=4)
+    z = np.arange(nz + 1) * vz
+    expect = n * (np.exp(-mu_a * z[:-1]) - np.exp(-mu_a * z[1:]))
+    sigma = np.sqrt(expect)
+    assert np.all(np.abs(g[:, 0, 0] - expect) < 5 * sigma + 1)
+    assert abs(c["steps"] / n - 1.0) < 1e-12  # one interaction per photon: w -> 0 at the first site
+
+
+def test_mean_free_path_and_first_moment():
+    # non-absorbing forward-peaked medium in a thick slab: steps until escape are many; check <s> via depth of
+    # first interaction: all weight of the first deposit column ~ exponential with 1/mu_t
+    mu_a, mu_s = 0.5, 4.5
+    prob = S.Problem([(mu_a, mu_s, 0.0, 1.0)], (1, 1, 400), (-50.0, -50.0, 0.0), (100.0, 100.0, 0.01),
+                     layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]), max_steps=1)
+    n = 200000
+    g, _, c = prob.oracle().run(n, seed=9, threads=4)
+    col = g[:, 0, 0] / (mu_a / (mu_a + mu_s))   # deposits -> interaction counts (w = 1 at the first site)
+    zc = (np.arange(400) + 0.5) * 0.01
+    mean_s = (col * zc).sum() / col.sum()
+    # truncated at 4 mm = 20 mfp: bias < 1e-8
+    assert abs(mean_s - 1.0 / (mu_a + mu_s)) < 4 * (1.0 / (mu_a + mu_s)) / np.sqrt(n) + 0.005  # + half-voxel binning
+
+
+def test_infinite_medium_absorbs_everything():
+    prob = S.Problem([(0.5, 5.0, 0.8, 1.0)], (4, 4, 4), (-1e6, -1e6, -1e6), (5e5, 5e5, 5e5),
+                     layers=dict(z_bounds=[-1e9, np.inf], medium_idx=[0]))
+    _, _, c = prob.oracle().run(4000, seed=2)
+    assert c["w_escaped_top"] == 0 and c["w_lost_outside_grid"] == 0
+    assert abs(c["w_absorbed"] + c["w_roulette_net"] - 4000) < 1e-8
+
+
+def test_pencil_beam_symmetry():
+    # odd voxel count: the beam axis runs through the middle of column 16, which is left out of the halves
+    g, _, _ = S.slab(n=33, voxel=0.8).oracle().run(60000, seed=4, threads=4)
+    a, b = g[:, :, :16].sum(), g[:, :, 17:].sum()   # -x vs +x
+    c, d = g[:, :16, :].sum(), g[:, 17:, :].sum()   # -y vs +y
+    assert abs(a - b) / (a + b) < 0.02 and abs(c - d) / (c + d) < 0.02
+    assert abs((a + b) - (c + d)) / (a + b) < 0.02
+
+
+def test_mcml_published_slab():
+    """Wang, Jacques & Zheng 1995, Table 1: n = 1, mu_a = 10, mu_s = 90 /cm, g = 0.75, d = 0.02 cm:
+    Rd = 0.09734 +- 0.00035, Tt = 0.66096 +- 0.00020 (literature values, not from the reference)."""
+    prob = S.slab(media=((10.0, 90.0, 0.75, 1.0),), thickness=0.02, n=8, voxel=0.0025)
+    n = 1500000
+    _, _, c = prob.oracle().run(n, seed=1, threads=8)
+    assert abs(c["w_escaped_top"] / n - 0.09734) < 0.0012
+    assert abs(c["w_escaped_bottom"] / n - 0.66096) < 0.0015
+
+
+def test_mcml_published_mismatched_semi_infinite():
+    """MCML paper Table 2 (Giovanelli): semi-infinite, n = 1.5, mu_a = 10, mu_s = 90, g = 0 (isotropic):
+    total reflectance (specular 0.04 included) = 0.2600; MCML itself reports 0.25907 +- 0.00170."""
+    prob = S.slab(media=((10.0, 90.0, 0.0, 1.5),), n=8, voxel=1.0)
+    n = 400000
+    _, _, c = prob.oracle().run(n, seed=5, threads=8)
+    assert abs(c["w_specular"] / n - 0.04) < 1e-12
+    assert abs((c["w_escaped_top"] + c["w_specular"]) / n - 0.2600) < 0.003
+
+
+def test_table_mode_equals_stream_semantics():
+    """Table RNG addresses uniforms by (photon, step): permuting photons permutes nothing else."""
+    prob = S.slab()
+    tab = np.random.RandomState(0).rand(300, 400, 4)
+    g1, _, c1 = prob.oracle().run(300, rng_table=tab)
+    g2, _, c2 = prob.oracle().run(300, rng_table=tab[::-1].copy())
+    assert c1["steps"] == c2["steps"]
+    np.testing.assert_allclose(g1, g2, rtol=1e-12, atol=1e-13)
+    # a table too short for a photon caps it: weight lands in w_capped and is conserved
+    g3, _, c3 = prob.oracle().run(300, rng_table=tab[:, :50].copy())
+    assert c3["w_capped"] > 0 and abs(O.conservation_residual(c3)) < 1e-9
+
+
+def test_threads_and_shards_agree_bitwise_in_fixed_point():
+    prob = S.two_layer(n=32)
+    _, fx1, c1 = prob.oracle().run(4000, seed=8, want_fx=True)
+    _, fx2, c2 = prob.oracle().run(4000, seed=8, want_fx=True, threads=5)
+    assert np.array_equal(fx1, fx2) and c1["steps"] == c2["steps"]
+    _, fa, _ = prob.oracle().run(1500, seed=8, photon_offset=0, want_fx=True)
+    _, fb, _ = prob.oracle().run(2500, seed=8, photon_offset=1500, want_fx=True)
+    assert np.array_equal(fa + fb, fx1)
+
+
+def test_f32_oracle_tracks_f64_statistically():
+    prob = S.slab()
+    g64, _, c64 = prob.oracle().run(20000, seed=6, threads=4)
+    g32, _, c32 = prob.oracle().run(20000, seed=6, threads=4, walk_f32=True)
+    assert abs(c64["w_absorbed"] - c32["w_absorbed"]) / 20000 < 0.01
+    assert abs(O.conservation_residual(c32)) < 2e-6 * 20000
