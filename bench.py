@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the photon-transport hot path (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete job of config C2 on every rank: zero the tally, trace
+1e7 photons (homogeneous semi-infinite slab mu_a=0.1 mu_s=10 g=0.9 n=1, 256^3 grid
+of 0.1 mm voxels, pencil beam, f64 walk, XORWOW, f64 tally) and -- for N > 1 --
+sum-reduce the voxel grid + counters to rank 0 with RCCL.  Ranks trace disjoint
+photon-id ranges (weak scaling: 1e7 photons per GPU); there is no other
+collective.  Inputs are synthetic by nature (the scene is ~100 bytes of constants,
+resident in HBM before the timed region).
+
+Prints ONE JSON line on rank 0:  metric = photon-steps/s over all ranks, plus
+  roofline      algorithmic tally bytes (16 B per photon-step for the f64 tally:
+                8 B read + 8 B write of one voxel) / kernel time from HIP events
+                on the kernel's own stream, against the 8 TB/s HBM peak;
+  cpu_baseline  the CPU oracle (oracle/, a port -- the reference has no such
+                path) on all host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PHOTONS = 10 ** 7
+GRID_N, VOXEL = 256, 0.1
+MEDIUM = (0.1, 10.0, 0.9, 1.0)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_STEP = {"f32": 8, "f64": 16, "u64fx": 16}
+
+
+def configure(ctx, tally):
+    half = GRID_N * VOXEL / 2
+    ctx.set_media([MEDIUM])
+    ctx.set_layers([0.0, np.inf], [0], 1.0, 1.0)
+    ctx.set_grid((GRID_N,) * 3, (-half, -half, 0.0), (VOXEL,) * 3, tally)
+    ctx.set_source(0, (0.0, 0.0, 0.0), (0.0, 0.0, 1.0))
+
+
+def cpu_baseline(target_seconds=12.0):
+    """CPU oracle (port) on every host core, bounded sample of C2."""
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    half = GRID_N * VOXEL / 2
+    sc = O.OracleScene([MEDIUM], (GRID_N,) * 3, (-half, -half, 0.0), (VOXEL,) * 3,
+                       layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))
+    t0 = time.perf_counter()
+    _, _, c = sc.run(50000, seed=0, threads=cores)
+    probe = time.perf_counter() - t0
+    rate = c["steps"] / probe
+    n = int(min(N_PHOTONS, max(100000, target_seconds * rate / 281.0)))
+    t0 = time.perf_counter()
+    _, _, c = sc.run(n, seed=0, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": c["steps"] / dt, "unit": "photon-steps/s", "cores": cores, "kind": "port",
+            "sample": "first %d photons of the same C2 workload (f64, 256^3 f64 grid), %.1f s wall, pthreads" % (n, dt),
+            "photons_per_sec": n / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--photons", type=int, default=N_PHOTONS, help="photons per GPU per step (default: C2's 1e7)")
+    ap.add_argument("--tally", default="f64", choices=["f32", "f64", "u64fx"])
+    ap.add_argument("--f32-walk", action="store_true", help="f32 walk arithmetic (default f64, the reference's dtype)")
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1 or "RANK" in os.environ
+    if args.gpus != world and distributed:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and not distributed:
+        raise SystemExit("for N > 1 launch through torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import light_transport_amd as lt
+    from light_transport_amd import distributed as ltd
+    ctx = lt.Context(local_rank)
+    configure(ctx, args.tally)
+    if args.blocks_per_cu or args.threads:
+        ctx.set_launch_config(args.blocks_per_cu, args.threads)
+    info = ctx.device_info()
+    per_gpu = args.photons
+    offset = rank * per_gpu     # disjoint id ranges; streams depend on (seed, id) only
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kernel_ms, steps_per_launch = [], []
+
+    def one_step(seed):
+        ctx.zero_tally()
+        ctx.launch(per_gpu, seed=seed, photon_offset=offset, f32_walk=args.f32_walk)
+        if distributed:
+            ltd.reduce_device(ctx, dst=0)       # RCCL sum of grid + counters to rank 0
+        else:
+            ctx.sync()
+
+    for w in range(args.warmup):
+        one_step(1000 + w)
+    barrier()
+    t0 = time.perf_counter()
+    total_steps_local = 0
+    for k in range(args.steps):
+        one_step(k)
+        kernel_ms.append(ctx.last_kernel_ms())
+        # photon-steps of this launch: rank 0 holds the reduced sum, other ranks their own
+        c = ctx.read_counters()
+        steps_per_launch.append(c["steps"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # NOTE: read_counters above is a 96-byte D2H inside the timed region (part of "tally readback")
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        km = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        kernel_avg_ms = float(km.item())
+    else:
+        kernel_avg_ms = float(np.mean(kernel_ms))
+
+    if rank == 0:
+        total_steps = int(np.sum(steps_per_launch))          # reduced over ranks when distributed
+        value = total_steps / elapsed
+        steps_one_launch = total_steps / args.steps / world  # per rank per launch
+        achieved = steps_one_launch * BYTES_PER_STEP[args.tally] / (kernel_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("%s_%s" % ("f32walk" if args.f32_walk else "f64walk", args.tally))
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "photon_steps_per_sec", "value": value, "unit": "photon-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.f32_walk else "f64", "data": "synthetic",
+            "photons_per_sec": world * per_gpu * args.steps / elapsed,
+            "config": {"workload": "C2: %.0e photons per GPU, homogeneous semi-infinite slab (mu_a=0.1, mu_s=10, g=0.9, "
+                                   "n=1), %d^3 voxel grid (%.1f mm), pencil beam" % (per_gpu, GRID_N, VOXEL),
+                       "tally": args.tally, "rng": "rocRAND XORWOW, re-seeded per photon",
+                       "parallelism": "photon-id sharding x%d, RCCL reduce of the grid to rank 0 per step" % world
+                       if world > 1 else "single GPU", "device": info["name"], "cus": info["cus"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "walk_kernel", "kernel_ms": kernel_avg_ms,
+                         "algorithmic_bytes_per_launch": steps_one_launch * BYTES_PER_STEP[args.tally],
+                         "atomics_per_sec": steps_one_launch / (kernel_avg_ms * 1e-3)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
