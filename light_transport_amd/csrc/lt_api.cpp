@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -413,6 +414,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     v.mesh = c->have_mesh ? 1 : 0;
     v.table = rng_table ? 1 : 0;
     v.tally = c->tally;
+    if (std::getenv("LT_DIAG_NO_TALLY")) v.tally = 3;  // diagnostic: time the walk without deposition
     if (v.table && v.f32) return c->fail(LT_E_UNSUPPORTED, "lt_launch: table RNG runs the f64 walk only");
     if (v.table && v.tally == LT_TALLY_F32) return c->fail(LT_E_UNSUPPORTED, "lt_launch: table RNG needs an f64 or u64fx tally");
     if (v.table && table_steps == 0) return c->fail(LT_E_INVALID, "lt_launch: table_steps == 0");

@@ -309,19 +309,24 @@ LT_DEV unsigned long long mix_seed(unsigned long long seed, unsigned long long p
 // ---------------------------------------------------------------------------
 // tally
 // ---------------------------------------------------------------------------
-template <int TALLY, typename R> LT_DEV void tally_add(void* grid, size_t idx, R dw)
+// value type a deposit is accumulated in before it is sent to memory
+template <int TALLY> struct TallyT { typedef double type; };
+template <> struct TallyT<LT_TALLY_F32> { typedef float type; };
+template <> struct TallyT<LT_TALLY_U64FX> { typedef unsigned long long type; };
+#define LT_TALLY_NONE 3  /* diagnostic build of the walk without deposition (not part of the ABI) */
+
+template <int TALLY, typename R> LT_DEV typename TallyT<TALLY>::type tally_quantum(R dw)
 {
-    if constexpr (TALLY == LT_TALLY_F32) {
-        __hip_atomic_fetch_add(reinterpret_cast<float*>(grid) + idx, (float)dw, __ATOMIC_RELAXED,
+    if constexpr (TALLY == LT_TALLY_U64FX) return (unsigned long long)((double)dw * LT_FX_SCALE + 0.5);
+    else return (typename TallyT<TALLY>::type)dw;
+}
+
+template <int TALLY> LT_DEV void tally_add(void* grid, unsigned idx, typename TallyT<TALLY>::type v)
+{
+    if constexpr (TALLY == LT_TALLY_NONE) { asm volatile("" ::"v"(idx), "v"(v)); }
+    else
+        __hip_atomic_fetch_add(reinterpret_cast<typename TallyT<TALLY>::type*>(grid) + idx, v, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-    } else if constexpr (TALLY == LT_TALLY_F64) {
-        __hip_atomic_fetch_add(reinterpret_cast<double*>(grid) + idx, (double)dw, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        unsigned long long q = (unsigned long long)((double)dw * LT_FX_SCALE + 0.5);
-        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(grid) + idx, q, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -409,6 +414,12 @@ __global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
     // per-lane accumulators of the frequent events
     double acc_abs = 0.0, acc_lost = 0.0;
     unsigned long long acc_steps = 0;
+    // run-length accumulation: consecutive deposits into the same voxel (a third of all steps when the
+    // voxel is one mean free path wide) are summed in registers and sent as ONE atomic request
+    typedef typename TallyT<TALLY>::type TV;
+    constexpr unsigned kNoVoxel = 0xffffffffu;
+    unsigned pend_idx = kNoVoxel;
+    TV pend_val = 0;
     // wave-level packet of photon ids [pk_next, pk_end)
     unsigned long long pk_next = 0, pk_end = 0;
     bool q_done = false;
@@ -589,8 +600,13 @@ __global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
                     const R dw = w * Mp->absorb;
                     const R fx = (px - gx0) * ivx, fy = (py - gy0) * ivy, fz = (pz - gz0) * ivz;
                     if (fx >= 0 && fx < fnx && fy >= 0 && fy < fny && fz >= 0 && fz < fnz) {
-                        size_t idx = ((size_t)(int)fz * (size_t)P.ny + (size_t)(int)fy) * (size_t)P.nx + (size_t)(int)fx;
-                        tally_add<TALLY, R>(P.grid, idx, dw);
+                        const unsigned idx = ((unsigned)(int)fz * (unsigned)P.ny + (unsigned)(int)fy) * (unsigned)P.nx + (unsigned)(int)fx;
+                        const TV q = tally_quantum<TALLY, R>(dw);
+                        if (idx == pend_idx) pend_val += q;
+                        else {
+                            if (pend_idx != kNoVoxel) tally_add<TALLY>(P.grid, pend_idx, pend_val);
+                            pend_idx = idx; pend_val = q;
+                        }
                         acc_abs += (double)dw;
                     } else {
                         acc_lost += (double)dw;
@@ -610,6 +626,8 @@ __global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
             }
         }
     }
+
+    if (pend_idx != kNoVoxel) tally_add<TALLY>(P.grid, pend_idx, pend_val);
 
     // ---------------- flush counters ----------------
     const double wa = wave_sum(acc_abs), wl = wave_sum(acc_lost);
@@ -639,6 +657,7 @@ static WalkFn pick_tally(int tally)
     case LT_TALLY_F32: if constexpr (!TABLE) return walk_kernel<R, MESH, TABLE, LT_TALLY_F32>; else return nullptr;
     case LT_TALLY_F64: return walk_kernel<R, MESH, TABLE, LT_TALLY_F64>;
     case LT_TALLY_U64FX: return walk_kernel<R, MESH, TABLE, LT_TALLY_U64FX>;
+    case LT_TALLY_NONE: if constexpr (!TABLE && !MESH) return walk_kernel<R, MESH, TABLE, LT_TALLY_NONE>; else return nullptr;
     }
     return nullptr;
 }
