@@ -24,6 +24,9 @@
 
 using namespace ltk;
 
+// mesh tables up to this size are staged into LDS by every workgroup; larger meshes are traversed in place
+static const size_t kMeshLdsBudget = 64 * 1024;
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -157,7 +160,14 @@ void fill_nodes(const std::vector<lt_bvh_node>& in, std::vector<NodeD<R>>& out)
         out[i].offset = in[i].offset;
         out[i].n_prims = in[i].n_prims;
         out[i].axis = in[i].axis;
-        out[i].pad_ = 0;
+        out[i].skip = (int32_t)in.size();
+    }
+    // skip links: pre-order layout => left child = i + 1 ends where the right child (offset) begins,
+    // the right child ends where its parent does (parents come before children, so one forward sweep)
+    for (size_t i = 0; i < in.size(); i++) {
+        if (in[i].n_prims > 0) continue;
+        out[i + 1].skip = in[i].offset;
+        out[(size_t)in[i].offset].skip = out[i].skip;
     }
 }
 
@@ -456,8 +466,12 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     LaunchCfg cfg;
     cfg.threads = c->threads_per_block > 0 ? c->threads_per_block : 256;
     cfg.lds_bytes = walk_lds_bytes(v, P.n_media, P.n_layers, P.n_tris, P.n_nodes);
-    if (cfg.lds_bytes > 160 * 1024)
-        return c->fail(LT_E_UNSUPPORTED, "lt_launch: scene tables need %zu B of LDS (> 160 KiB per CU)", cfg.lds_bytes);
+    if (v.mesh && cfg.lds_bytes > kMeshLdsBudget) {
+        // large mesh: leave triangles and nodes in global memory (L2 / Infinity Cache resident)
+        if (v.table) return c->fail(LT_E_UNSUPPORTED, "lt_launch: table RNG with a mesh beyond the LDS budget");
+        v.mesh = 2;
+        cfg.lds_bytes = walk_lds_bytes(v, P.n_media, P.n_layers, P.n_tris, P.n_nodes);
+    }
     int resident = walk_max_blocks_per_cu(v, cfg.threads, cfg.lds_bytes);
     if (resident <= 0) return c->fail(LT_E_HIP, "lt_launch: kernel variant not resident (occupancy query returned %d)", resident);
     int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : resident;

@@ -27,7 +27,8 @@ struct TriD {
 template <typename R>
 struct NodeD {
     R lo[3], hi[3];
-    int32_t offset, n_prims, axis, pad_;
+    int32_t offset, n_prims, axis;
+    int32_t skip;  // first node after this node's subtree (stackless traversal)
 };
 
 struct DevCounters {
@@ -73,7 +74,7 @@ struct LaunchCfg {
 // walk variants: precision x geometry x rng are compile-time, tally is too
 struct Variant {
     int f32;     // 0: f64 walk, 1: f32 walk
-    int mesh;    // 0: layered slab, 1: triangle mesh + BVH
+    int mesh;    // 0: layered slab, 1: mesh + BVH staged in LDS, 2: mesh + BVH read from global memory
     int table;   // 0: XORWOW, 1: table RNG
     int tally;   // LT_TALLY_*
 };

@@ -135,37 +135,32 @@ LT_DEV void consider(const TriD<R>* tris, int i, const R* o, const R* d, int& bi
     }
 }
 
-constexpr int kStack = 32;
-
+// Stackless pre-order walk: nodes are stored in DFS order and every node carries the index of the first
+// node AFTER its subtree (NodeD::skip, filled on the host), so a missed box or a finished leaf jumps there and
+// a hit interior node simply continues with cur + 1.  No per-lane stack, no VGPR-indexed arrays; the result
+// (nearest hit, ties to the lower primitive index) does not depend on the visiting order.
 template <typename R>
 LT_DEV void nearest_bvh(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes, const R* o,
                         const R* d, R tmax, int& prim, R& t_out)
 {
     int bi = -1; R bt = tmax;
-    if (n_nodes > 0) {
-        R inv_d[3] = {(R)1 / d[0], (R)1 / d[1], (R)1 / d[2]};  // S/bvh_new.py:418
-        const bool neg[3] = {inv_d[0] < 0, inv_d[1] < 0, inv_d[2] < 0};
-        const R slack = box_widen<R>();
-        int stack[kStack]; int sp = 0; int cur = 0;
-        for (;;) {
-            const NodeD<R>* nd = &nodes[cur];
-            R lo[3] = {nd->lo[0], nd->lo[1], nd->lo[2]};
-            R hi[3] = {nd->hi[0], nd->hi[1], nd->hi[2]};
-            if (box_hit(lo, hi, o, inv_d, bt * slack)) {
-                const int np = nd->n_prims, off = nd->offset;
-                if (np > 0) {
-                    for (int k = 0; k < np; k++) consider(tris, off + k, o, d, bi, bt);
-                    if (sp == 0) break;
-                    cur = stack[--sp];
-                } else if (neg[nd->axis]) {  // S/bvh_new.py:455-458
-                    stack[sp++] = cur + 1; cur = off;
-                } else {
-                    stack[sp++] = off; cur = cur + 1;
-                }
+    const R inv_d[3] = {(R)1 / d[0], (R)1 / d[1], (R)1 / d[2]};  // S/bvh_new.py:418
+    const R slack = box_widen<R>();
+    int cur = 0;
+    while (cur < n_nodes) {
+        const NodeD<R>* nd = &nodes[cur];
+        const R lo[3] = {nd->lo[0], nd->lo[1], nd->lo[2]};
+        const R hi[3] = {nd->hi[0], nd->hi[1], nd->hi[2]};
+        const int np = nd->n_prims, off = nd->offset, skip = nd->skip;
+        if (box_hit(lo, hi, o, inv_d, bt * slack)) {
+            if (np > 0) {
+                for (int k = 0; k < np; k++) consider(tris, off + k, o, d, bi, bt);
+                cur = skip;
             } else {
-                if (sp == 0) break;
-                cur = stack[--sp];
+                cur = cur + 1;
             }
+        } else {
+            cur = skip;
         }
     }
     prim = bi; t_out = bi >= 0 ? bt : Mx<R>::inf();
@@ -377,24 +372,29 @@ constexpr unsigned kPacket = 64;  // photon ids taken from the global queue per 
 // ---------------------------------------------------------------------------
 // the walk kernel
 // ---------------------------------------------------------------------------
-template <typename R, bool MESH, bool TABLE, int TALLY>
+template <typename R, int GEOM, bool TABLE, int TALLY>
 __global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
 {
+    constexpr bool MESH = GEOM != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const LdsLayout<R> L(P.n_media, P.n_layers, P.n_tris, P.n_nodes);
+    // GEOM 2: the mesh is too large for LDS -> triangles and nodes are read from global memory (they are
+    // read-only and shared by every wave, so they live in the XCD L2s / Infinity Cache after first touch)
+    const LdsLayout<R> L(P.n_media, P.n_layers, GEOM == 1 ? P.n_tris : 0, GEOM == 1 ? P.n_nodes : 0);
     double* s_cnt = reinterpret_cast<double*>(lds_raw + L.off_cnt);
     const MedD<R>* s_med = reinterpret_cast<const MedD<R>*>(lds_raw + L.off_media);
     const R* s_zb = reinterpret_cast<const R*>(lds_raw + L.off_zb);
     const int32_t* s_lm = reinterpret_cast<const int32_t*>(lds_raw + L.off_lm);
-    const TriD<R>* s_tris = reinterpret_cast<const TriD<R>*>(lds_raw + L.off_tris);
-    const NodeD<R>* s_nodes = reinterpret_cast<const NodeD<R>*>(lds_raw + L.off_nodes);
+    const TriD<R>* s_tris = GEOM == 2 ? reinterpret_cast<const TriD<R>*>(P.tris)
+                                      : reinterpret_cast<const TriD<R>*>(lds_raw + L.off_tris);
+    const NodeD<R>* s_nodes = GEOM == 2 ? reinterpret_cast<const NodeD<R>*>(P.nodes)
+                                        : reinterpret_cast<const NodeD<R>*>(lds_raw + L.off_nodes);
 
     if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0.0;
     lds_copy(lds_raw + L.off_media, P.media, (size_t)P.n_media * sizeof(MedD<R>));
     if constexpr (!MESH) {
         lds_copy(lds_raw + L.off_zb, P.zb, (size_t)(P.n_layers + 1) * sizeof(R));
         lds_copy(lds_raw + L.off_lm, P.layer_medium, (size_t)P.n_layers * sizeof(int32_t));
-    } else {
+    } else if constexpr (GEOM == 1) {
         lds_copy(lds_raw + L.off_tris, P.tris, (size_t)P.n_tris * sizeof(TriD<R>));
         lds_copy(lds_raw + L.off_nodes, P.nodes, (size_t)P.n_nodes * sizeof(NodeD<R>));
     }
@@ -650,31 +650,36 @@ __global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
 // ---------------------------------------------------------------------------
 typedef void (*WalkFn)(const WalkParams);
 
-template <typename R, bool MESH, bool TABLE>
+template <typename R, int GEOM, bool TABLE>
 static WalkFn pick_tally(int tally)
 {
     switch (tally) {
-    case LT_TALLY_F32: if constexpr (!TABLE) return walk_kernel<R, MESH, TABLE, LT_TALLY_F32>; else return nullptr;
-    case LT_TALLY_F64: return walk_kernel<R, MESH, TABLE, LT_TALLY_F64>;
-    case LT_TALLY_U64FX: return walk_kernel<R, MESH, TABLE, LT_TALLY_U64FX>;
-    case LT_TALLY_NONE: if constexpr (!TABLE && !MESH) return walk_kernel<R, MESH, TABLE, LT_TALLY_NONE>; else return nullptr;
+    case LT_TALLY_F32: if constexpr (!TABLE) return walk_kernel<R, GEOM, TABLE, LT_TALLY_F32>; else return nullptr;
+    case LT_TALLY_F64: return walk_kernel<R, GEOM, TABLE, LT_TALLY_F64>;
+    case LT_TALLY_U64FX: return walk_kernel<R, GEOM, TABLE, LT_TALLY_U64FX>;
+    case LT_TALLY_NONE: if constexpr (!TABLE && GEOM == 0) return walk_kernel<R, GEOM, TABLE, LT_TALLY_NONE>; else return nullptr;
     }
     return nullptr;
 }
 
+template <typename R, bool TABLE>
+static WalkFn pick_geom(const Variant& v)
+{
+    if (v.mesh == 0) return pick_tally<R, 0, TABLE>(v.tally);
+    if (v.mesh == 1) return pick_tally<R, 1, TABLE>(v.tally);
+    if constexpr (!TABLE) return pick_tally<R, 2, TABLE>(v.tally); else return nullptr;
+}
+
 static WalkFn pick(const Variant& v)
 {
-    if (v.f32) {
-        if (v.table) return nullptr;
-        return v.mesh ? pick_tally<float, true, false>(v.tally) : pick_tally<float, false, false>(v.tally);
-    }
-    if (v.table) return v.mesh ? pick_tally<double, true, true>(v.tally) : pick_tally<double, false, true>(v.tally);
-    return v.mesh ? pick_tally<double, true, false>(v.tally) : pick_tally<double, false, false>(v.tally);
+    if (v.f32) return v.table ? nullptr : pick_geom<float, false>(v);
+    return v.table ? pick_geom<double, true>(v) : pick_geom<double, false>(v);
 }
 
 size_t walk_lds_bytes(const Variant& v, int n_media, int n_layers, int n_tris, int n_nodes)
 {
-    if (v.mesh) n_layers = 0; else { n_tris = 0; n_nodes = 0; }
+    if (v.mesh) n_layers = 0;
+    if (v.mesh != 1) { n_tris = 0; n_nodes = 0; }
     return v.f32 ? LdsLayout<float>(n_media, n_layers, n_tris, n_nodes).total
                  : LdsLayout<double>(n_media, n_layers, n_tris, n_nodes).total;
 }

@@ -1,0 +1,53 @@
+"""Wavefront OBJ ingest without pywavefront / pyvista.
+
+Role of src/io.py:11-40 of the reference (``load_obj`` via pywavefront into legacy
+``Triangle`` objects, with a stale ``Material(...)`` call).  This loader reads the
+forms found in the reference's own assets (examples/obj/*.obj): ``v x y z``,
+``f a b c``, ``f a b c d ...`` (fan-triangulated), ``f a/t``, ``f a//n``,
+``f a/t/n`` and negative (relative) indices; everything else (vt, vn, g, o, s,
+usemtl, mtllib) is skipped.  It returns ``PreComputedTriangle`` objects, the
+primitive the BVH builder and the photon walk consume.
+"""
+import numpy as np
+
+from .primitives import PreComputedTriangle
+
+
+def read_obj(path):
+    """-> (vertices [V, 3] float64, faces [F, 3] int64), polygons fan-triangulated."""
+    verts, faces = [], []
+    with open(path, "r", errors="replace") as fh:
+        for line in fh:
+            if line.startswith("v "):
+                p = line.split()
+                verts.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("f "):
+                idx = []
+                for tok in line.split()[1:]:
+                    i = int(tok.split("/")[0])
+                    idx.append(i - 1 if i > 0 else len(verts) + i)
+                for k in range(1, len(idx) - 1):
+                    faces.append((idx[0], idx[k], idx[k + 1]))
+    v = np.asarray(verts, dtype=np.float64).reshape(-1, 3)
+    f = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    if f.size and (f.min() < 0 or f.max() >= len(v)):
+        raise ValueError("%s: face index out of range" % path)
+    return v, f
+
+
+def triangles_from_mesh(vertices, faces, material, scale=1.0, translate=(0.0, 0.0, 0.0), drop_degenerate=True):
+    v = np.asarray(vertices, dtype=np.float64) * float(scale) + np.asarray(translate, dtype=np.float64)
+    out = []
+    for a, b, c in np.asarray(faces, dtype=np.int64):
+        if drop_degenerate:
+            n = np.cross(v[b] - v[a], v[c] - v[a])
+            if not np.dot(n, n) > 0.0:
+                continue
+        out.append(PreComputedTriangle(v[a], v[b], v[c], material))
+    return out
+
+
+def load_obj(path, material, scale=1.0, translate=(0.0, 0.0, 0.0)):
+    """Reference call shape ``load_obj(path, ...)`` -> list of primitives."""
+    v, f = read_obj(path)
+    return triangles_from_mesh(v, f, material, scale, translate)

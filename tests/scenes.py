@@ -78,3 +78,51 @@ def assert_grid_close(g, go, rtol=1e-9, atol=1e-12, max_bad=0):
     d = np.abs(g - go)
     bad = int((d > atol + rtol * np.abs(go)).sum())
     assert bad <= max_bad, "%d voxels outside |d| <= %g + %g*E (max abs %g)" % (bad, atol, rtol, d.max())
+
+
+def icosphere(subdiv=3, radius=1.0, center=(0.0, 0.0, 0.0)):
+    """(vertices, faces) of a subdivided icosahedron, outward-facing: 20 * 4^subdiv triangles."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10),
+         (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[k] = len(v) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.array(v) * radius + np.asarray(center, dtype=np.float64), np.array(f, dtype=np.int64)
+
+
+def sphere_in_box(subdiv=4, n=48, split_method=0, **kw):
+    """f1 scene: a finely tessellated sphere (20 * 4^subdiv triangles; 5120 at subdiv 4 -- beyond the LDS
+    budget, so the walk traverses it in global memory) of an absorbing medium inside a closed box."""
+    from light_transport_amd.src.io import triangles_from_mesh
+    dim = 4.0
+    walls = cb.get_cornell_box(dim, K.GLASS_MAT, K.GLASS_MAT, K.GLASS_MAT) + cb.get_front_wall(dim, K.GLASS_MAT) \
+        + cb.get_light_quad(dim, K.GLASS_MAT)
+    for t in walls:
+        t.med_front, t.med_back = 0, -1
+    vs, fs = icosphere(subdiv, 1.5, (0.3, -0.2, 0.1))
+    ball = triangles_from_mesh(vs, fs, K.GLASS_MAT)
+    for t in ball:
+        t.med_front, t.med_back = 0, 1
+    ordered, linear = B.build_linear_bvh(walls + ball, split_method)
+    mesh = dict(verts=B.triangles_array(ordered), med_front=np.array([t.med_front for t in ordered], np.int32),
+                med_back=np.array([t.med_back for t in ordered], np.int32), nodes=B.linear_bvh_arrays(linear))
+    media = [(0.05, 5.0, 0.8, 1.0), (0.8, 8.0, 0.9, 1.37)]
+    src = dict(type=1, pos=(-1.0, dim, -1.0), dir=(0.0, -1.0, 0.0), extra=(2.0, 0.0, 0.0, 0.0, 0.0, 2.0), start_medium=0)
+    voxel = 2 * dim / n
+    return Problem(media, (n, n, n), (-dim, -dim, -dim), (voxel,) * 3, mesh=mesh, source=src, **kw), ordered, linear

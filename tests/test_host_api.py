@@ -160,3 +160,32 @@ def test_photon_tracing_objects():
         PT.LayeredSlab([], [])
     prob = S.cornell(16)
     assert prob.mesh["verts"].shape == (30, 3, 3) and set(prob.mesh["med_back"]) == {-1, 1}
+
+
+def test_obj_loader(tmp_path):
+    from light_transport_amd.src.io import load_obj, read_obj
+    p = tmp_path / "m.obj"
+    p.write_text("# comment\no thing\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\nvn 0 0 1\nvt 0 0\n"
+                 "f 1 2 3 4\nf 1//1 2//1 5//1\nf 1/1/1 3/1/1 5/1/1\nf -5 -4 -1\ns off\nusemtl x\n")
+    v, f = read_obj(str(p))
+    assert v.shape == (5, 3) and f.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 4], [0, 2, 4], [0, 1, 4]]
+    tris = load_obj(str(p), K.GLASS_MAT, scale=2.0, translate=(1, 0, 0))
+    assert len(tris) == 5 and np.allclose(tris[0].vertex_2[:3], [3, 0, 0]) and tris[0].vertex_2[3] == 1.0
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nf 1 2 3\n")
+    with pytest.raises(ValueError):
+        read_obj(str(tmp_path / "bad.obj"))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference assets only exist in the build container")
+def test_obj_loader_on_reference_assets():
+    """Face/vertex counts of the reference's own OBJ files (Assets)."""
+    from light_transport_amd.src.io import read_obj
+    d = "/root/reference/LightTransportSimulator/light_transport/examples/obj/"
+    v, f = read_obj(d + "cube.obj")
+    assert len(v) == 8 and len(f) == 12            # 6 quads -> 12 triangles
+    v, f = read_obj(d + "teapot.obj")
+    assert len(v) == 3644 and len(f) == 6320
+    v, f = read_obj(d + "cow.obj")
+    assert len(v) == 4583 and len(f) == 5804
+    v, f = read_obj(d + "pumpkin.obj")
+    assert len(v) == 5002 and len(f) == 10000
