@@ -209,6 +209,42 @@ int lt_eval(lt_ctx* ctx, int fn, const double* in, size_t n, double* out);
 int lt_rng_raw(lt_ctx* ctx, uint64_t seed, uint64_t photon_id, uint32_t count,
                uint32_t* out);
 
+/* ---- surface path tracing on the same mesh ------------ */
+/* per-triangle surface record: the Material fields trace_path reads
+ * (material.py:28-37; path_tracing_fix1.py:45-119) + PreComputedTriangle.is_light */
+typedef struct lt_surface_material {
+    double diffuse[3];   /* material.color.diffuse */
+    double emission;
+    double ior;
+    double transmission;
+    int32_t is_diffuse, is_mirror, is_light, pad_;
+} lt_surface_material;
+
+/* one point sample of the area light: role of Light (scene.py:12-17).
+ * radiance = material.emission * material.color.diffuse (light_samples.py:56) */
+typedef struct lt_point_light {
+    double source[3];
+    double normal[3];
+    double radiance[3];
+    double total_area;
+} lt_point_light;
+
+/* one entry per triangle of the current mesh (lt_set_mesh order) */
+int lt_set_surface_materials(lt_ctx* ctx, const lt_surface_material* mats, int n_tris);
+int lt_set_lights(lt_ctx* ctx, const lt_point_light* lights, int n);
+/* role of render_scene + trace_path (path_tracing_fix1.py:18-169).  One lane
+ * per pixel.  xs[width] / ys[height]: screen coordinates (np.linspace of
+ * left..right / top..bottom, :141-142).  rand_0 / rand_1: the Scene tables
+ * [H][W][S][D] (scene.py:68-69); rand_0 is updated in place with the +inf
+ * markers the reference writes for unused bounces (:38,66,130).  light_choice
+ * [H][W][S][D]: index of the light sample used by the shadow ray of that bounce
+ * (the reference draws it with np.random.choice, light_samples.py:38).
+ * image [H][W][3] is ACCUMULATED into: += 0.25 * clip(mean colour) (:166). */
+int lt_render_surface(lt_ctx* ctx, int width, int height, int samples, int max_depth,
+                      const double camera[3], double f_distance, const double* xs,
+                      const double* ys, double* rand_0, const double* rand_1,
+                      const int32_t* light_choice, double* image);
+
 /* device description for bench reports */
 int lt_device_info(lt_ctx* ctx, char* name, size_t name_len, int* n_cus,
                    int* clock_mhz, size_t* hbm_bytes);

@@ -27,6 +27,7 @@ SYMBOLS = [
     "lt_last_kernel_ms", "lt_zero_tally", "lt_read_grid", "lt_read_grid_f64", "lt_read_counters",
     "lt_grid_device_ptr", "lt_counters_device_ptr", "lt_stream", "lt_reduce_grid", "lt_intersect_rays",
     "lt_triangle_intersect", "lt_intersect_bounds", "lt_eval", "lt_rng_raw", "lt_device_info",
+    "lt_set_surface_materials", "lt_set_lights", "lt_render_surface",
 ]
 
 
@@ -50,6 +51,39 @@ class Counters(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class SurfaceMaterial(C.Structure):
+    _fields_ = [("diffuse", C.c_double * 3), ("emission", C.c_double), ("ior", C.c_double),
+                ("transmission", C.c_double), ("is_diffuse", C.c_int32), ("is_mirror", C.c_int32),
+                ("is_light", C.c_int32), ("pad_", C.c_int32)]
+
+
+class PointLight(C.Structure):
+    _fields_ = [("source", C.c_double * 3), ("normal", C.c_double * 3), ("radiance", C.c_double * 3),
+                ("total_area", C.c_double)]
+
+
+def pack_surface_materials(primitives):
+    """lt_surface_material per primitive from the reference-style objects (Material + is_light)."""
+    arr = (SurfaceMaterial * max(len(primitives), 1))()
+    for i, p in enumerate(primitives):
+        m = p.material
+        arr[i].diffuse[:] = [float(x) for x in m.color.diffuse[:3]]
+        arr[i].emission, arr[i].ior, arr[i].transmission = float(m.emission), float(m.ior), float(m.transmission)
+        arr[i].is_diffuse, arr[i].is_mirror, arr[i].is_light = int(m.is_diffuse), int(m.is_mirror), int(p.is_light)
+    return arr
+
+
+def pack_lights(lights):
+    """lt_point_light per Light sample (scene.py:12-17); radiance = emission * color.diffuse."""
+    arr = (PointLight * max(len(lights), 1))()
+    for i, l in enumerate(lights):
+        arr[i].source[:] = [float(x) for x in l.source[:3]]
+        arr[i].normal[:] = [float(x) for x in l.normal[:3]]
+        arr[i].radiance[:] = [float(l.material.emission * x) for x in l.material.color.diffuse[:3]]
+        arr[i].total_area = float(l.total_area)
+    return arr
 
 
 _lib = None
@@ -275,6 +309,31 @@ class Context:
         out = np.empty((a.shape[0], k_out), dtype=np.float64)
         self._ck(lib().lt_eval(self._h, C.c_int(fn), _dp(a), C.c_size_t(a.shape[0]), _dp(out)), "lt_eval")
         return out
+
+    # -- surface path tracing (f2) ------------------------------------------
+    def set_surface_materials(self, mats):
+        self._ck(lib().lt_set_surface_materials(self._h, mats, C.c_int(len(mats))), "lt_set_surface_materials")
+
+    def set_lights(self, lights):
+        self._ck(lib().lt_set_lights(self._h, lights, C.c_int(len(lights))), "lt_set_lights")
+
+    def render_surface(self, camera, f_distance, xs, ys, rand_0, rand_1, light_choice, image):
+        """rand_0 [H,W,S,D] and image [H,W,3] are updated in place (C-contiguous float64)."""
+        H, W, S, D = rand_0.shape
+        for a in (rand_0, rand_1, image):
+            if a.dtype != np.float64 or not a.flags["C_CONTIGUOUS"]:
+                raise LtError("render_surface: tables and image must be C-contiguous float64")
+        lc = np.ascontiguousarray(light_choice, dtype=np.int32)
+        if rand_1.shape != rand_0.shape or lc.shape != rand_0.shape or image.shape != (H, W, 3):
+            raise LtError("render_surface: inconsistent table / image shapes")
+        cam = (C.c_double * 3)(*[float(x) for x in np.asarray(camera).ravel()[:3]])
+        xs, ys = _f64(xs), _f64(ys)
+        if xs.size != W or ys.size != H:
+            raise LtError("render_surface: xs / ys must have W / H entries")
+        self._ck(lib().lt_render_surface(self._h, C.c_int(W), C.c_int(H), C.c_int(S), C.c_int(D), cam,
+                                         C.c_double(f_distance), _dp(xs), _dp(ys), _dp(rand_0), _dp(rand_1), _ip(lc),
+                                         _dp(image)), "lt_render_surface")
+        return image
 
     def rng_raw(self, seed, photon_id, count):
         out = np.empty(count, dtype=np.uint32)

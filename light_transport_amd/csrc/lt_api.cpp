@@ -62,6 +62,8 @@ struct lt_ctx {
     std::vector<double> verts;
     std::vector<int32_t> med_front, med_back;
     std::vector<lt_bvh_node> nodes;
+    std::vector<lt_surface_material> surf_mats;
+    std::vector<lt_point_light> lights;
     bool have_layers = false, have_mesh = false, have_grid = false, have_source = false;
     int nx = 0, ny = 0, nz = 0, tally = LT_TALLY_F32;
     double origin[3] = {0, 0, 0}, voxel[3] = {1, 1, 1};
@@ -73,6 +75,7 @@ struct lt_ctx {
     // device buffers
     DevBuf d_media[2], d_zb[2], d_lm, d_tris[2], d_nodes[2];  // [0]=f64, [1]=f32
     DevBuf d_grid, d_counters, d_head, d_table, d_scratch_in, d_scratch_out, d_scratch_aux;
+    DevBuf d_mats, d_lights, d_r0, d_r1, d_lc, d_img, d_xy;
     bool tables_dirty = true;
     bool timed = false;
 
@@ -281,6 +284,8 @@ int lt_destroy(lt_ctx* c)
     for (int i = 0; i < 2; i++) { c->d_media[i].release(); c->d_zb[i].release(); c->d_tris[i].release(); c->d_nodes[i].release(); }
     c->d_lm.release(); c->d_grid.release(); c->d_counters.release(); c->d_head.release(); c->d_table.release();
     c->d_scratch_in.release(); c->d_scratch_out.release(); c->d_scratch_aux.release();
+    c->d_mats.release(); c->d_lights.release(); c->d_r0.release(); c->d_r1.release(); c->d_lc.release();
+    c->d_img.release(); c->d_xy.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -342,6 +347,7 @@ int lt_set_mesh(lt_ctx* c, const double* verts, const int32_t* med_front, const 
     c->med_back.assign(med_back, med_back + n_tris);
     c->nodes.swap(nn);
     c->have_mesh = true; c->have_layers = false;
+    c->surf_mats.clear();
     c->tables_dirty = true;
     return LT_OK;
 }
@@ -727,6 +733,76 @@ int lt_rng_raw(lt_ctx* c, uint64_t seed, uint64_t photon_id, uint32_t count, uin
     HIP_TRY(c, c->d_scratch_aux.ensure((size_t)count * 4));
     HIP_TRY(c, launch_rng_raw(seed, photon_id, count, (uint32_t*)c->d_scratch_aux.p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch_aux.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_set_surface_materials(lt_ctx* c, const lt_surface_material* mats, int n_tris)
+{
+    CHECK_CTX(c);
+    if (!c->have_mesh) return c->fail(LT_E_STATE, "lt_set_surface_materials: lt_set_mesh first");
+    if (!mats || n_tris != (int)c->med_front.size())
+        return c->fail(LT_E_INVALID, "lt_set_surface_materials: need one record per mesh triangle (%zu)", c->med_front.size());
+    c->surf_mats.assign(mats, mats + n_tris);
+    return LT_OK;
+}
+
+int lt_set_lights(lt_ctx* c, const lt_point_light* lights, int n)
+{
+    CHECK_CTX(c);
+    if (!lights || n <= 0) return c->fail(LT_E_INVALID, "lt_set_lights: need at least one light sample");
+    c->lights.assign(lights, lights + n);
+    return LT_OK;
+}
+
+int lt_render_surface(lt_ctx* c, int width, int height, int samples, int max_depth, const double camera[3],
+                      double f_distance, const double* xs, const double* ys, double* rand_0, const double* rand_1,
+                      const int32_t* light_choice, double* image)
+{
+    CHECK_CTX(c);
+    if (!c->have_mesh || c->surf_mats.empty() || c->lights.empty())
+        return c->fail(LT_E_STATE, "lt_render_surface: lt_set_mesh, lt_set_surface_materials and lt_set_lights first");
+    if (width <= 0 || height <= 0 || samples <= 0 || max_depth <= 0 || !camera || !xs || !ys || !rand_0 || !rand_1 ||
+        !light_choice || !image)
+        return c->fail(LT_E_INVALID, "lt_render_surface: bad argument");
+    const size_t n_tab = (size_t)width * height * samples * max_depth;
+    for (size_t k = 0; k < n_tab; k++)
+        if (light_choice[k] < 0 || light_choice[k] >= (int)c->lights.size())
+            return c->fail(LT_E_INVALID, "lt_render_surface: light_choice[%zu] out of range", k);
+    BIND(c);
+    if (c->media.empty()) { lt_medium m = {0, 0, 0, 1}; c->media.push_back(m); }
+    int rc = upload_tables(c);
+    if (rc) return rc;
+    const size_t n_img = (size_t)width * height * 3;
+    HIP_TRY(c, c->d_mats.ensure(c->surf_mats.size() * sizeof(lt_surface_material)));
+    HIP_TRY(c, c->d_lights.ensure(c->lights.size() * sizeof(lt_point_light)));
+    HIP_TRY(c, c->d_r0.ensure(n_tab * 8)); HIP_TRY(c, c->d_r1.ensure(n_tab * 8)); HIP_TRY(c, c->d_lc.ensure(n_tab * 4));
+    HIP_TRY(c, c->d_img.ensure(n_img * 8)); HIP_TRY(c, c->d_xy.ensure((size_t)(width + height) * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->d_mats.p, c->surf_mats.data(), c->surf_mats.size() * sizeof(lt_surface_material), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_lights.p, c->lights.data(), c->lights.size() * sizeof(lt_point_light), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_r0.p, rand_0, n_tab * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_r1.p, rand_1, n_tab * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_lc.p, light_choice, n_tab * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_img.p, image, n_img * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_xy.p, xs, (size_t)width * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync((double*)c->d_xy.p + width, ys, (size_t)height * 8, hipMemcpyHostToDevice, c->stream));
+    RenderParams P;
+    std::memset(&P, 0, sizeof P);
+    P.tris = c->d_tris[0].p; P.nodes = c->d_nodes[0].p;
+    P.mats = (const lt_surface_material*)c->d_mats.p; P.lights = (const lt_point_light*)c->d_lights.p;
+    P.n_tris = (int)c->med_front.size(); P.n_nodes = (int)c->nodes.size(); P.n_lights = (int)c->lights.size();
+    P.W = width; P.H = height; P.S = samples; P.D = max_depth;
+    for (int k = 0; k < 3; k++) P.cam[k] = camera[k];
+    P.f_distance = f_distance;
+    P.xs = (const double*)c->d_xy.p; P.ys = (const double*)c->d_xy.p + width;
+    P.rand_0 = (double*)c->d_r0.p; P.rand_1 = (const double*)c->d_r1.p; P.light_choice = (const int32_t*)c->d_lc.p;
+    P.image = (double*)c->d_img.p;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(c, launch_render_surface(P, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    HIP_TRY(c, hipMemcpyAsync(image, c->d_img.p, n_img * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(rand_0, c->d_r0.p, n_tab * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return LT_OK;
 }

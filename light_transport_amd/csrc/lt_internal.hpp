@@ -84,6 +84,23 @@ size_t walk_lds_bytes(const Variant& v, int n_media, int n_layers, int n_tris, i
 // resident-blocks-per-CU the runtime reports for a variant at `threads`
 int walk_max_blocks_per_cu(const Variant& v, int threads, size_t lds_bytes);
 
+struct RenderParams {
+    const void* tris;    // TriD<double>
+    const void* nodes;   // NodeD<double>
+    const lt_surface_material* mats;
+    const lt_point_light* lights;
+    int n_tris, n_nodes, n_lights;
+    int W, H, S, D;
+    double cam[3], f_distance;
+    const double* xs;
+    const double* ys;
+    double* rand_0;
+    const double* rand_1;
+    const int32_t* light_choice;
+    double* image;
+};
+hipError_t launch_render_surface(const RenderParams& P, hipStream_t s);
+
 hipError_t launch_intersect_rays(const void* tris, const void* nodes, int n_tris, int n_nodes,
                                  const double* o, const double* d, const double* tmax, size_t n,
                                  int use_bvh, int32_t* prim, double* t, hipStream_t s);

@@ -817,6 +817,123 @@ __global__ void k_grid_to_f64(const void* grid, int tally, size_t n, double* out
     }
 }
 
+// ---------------------------------------------------------------------------
+// surface path tracer: trace_path + render_scene of S/path_tracing_fix1.py:18-169,
+// one lane per pixel, samples looped in the lane (no atomics: a pixel has one owner)
+// ---------------------------------------------------------------------------
+LT_DEV void mark_unused(double* rand_0, size_t base, int from, int D)  // :36-38, :64-66, :128-130
+{
+    for (int b = from; b < D; b++) rand_0[base + b] = __builtin_huge_val();
+}
+
+__global__ void __launch_bounds__(64) k_render_surface(const RenderParams P)
+{
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= P.W * P.H) return;
+    const int i = pix / P.W, j = pix % P.W;
+    const TriD<double>* tris = reinterpret_cast<const TriD<double>*>(P.tris);
+    const NodeD<double>* nodes = reinterpret_cast<const NodeD<double>*>(P.nodes);
+    const double eps = 1e-6, inv_pi = 0.3183098861837907, inf = __builtin_huge_val();
+    double color[3] = {0, 0, 0};
+    for (int smp = 0; smp < P.S; smp++) {
+        const size_t base = (((size_t)i * P.W + j) * P.S + smp) * (size_t)P.D;
+        // camera ray, :152-160 (anti-alias jitter re-uses the bounce-0 uniform for x and y)
+        double o[3] = {P.cam[0], P.cam[1], P.cam[2]};
+        const double jit = P.rand_0[base];
+        double d[3] = {P.xs[j] + jit / (double)P.W - o[0], P.ys[i] + jit / (double)P.H - o[1], P.f_distance - o[2]};
+        normalize3(d);
+        double thr[3] = {1, 1, 1}, L[3] = {0, 0, 0};
+        for (int bounce = 0;;) {
+            if (bounce >= P.D) break;                                   // :24-26
+            const double r0 = P.rand_0[base + bounce], r1 = P.rand_1[base + bounce];
+            int prim; double t;
+            nearest_bvh(tris, nodes, P.n_nodes, o, d, inf, prim, t);    // hit_object, :32
+            if (prim < 0) { mark_unused(P.rand_0, base, bounce, P.D); break; }
+            const lt_surface_material M = P.mats[prim];
+            double n[3] = {tris[prim].n[0], tris[prim].n[1], tris[prim].n[2]};
+            const double X[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+            if (M.is_light) { L[0] += M.emission * thr[0]; L[1] += M.emission * thr[1]; L[2] += M.emission * thr[2]; }
+            bool inside = false;
+            if (dot3(n, d) > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; inside = true; }   // :48-51
+            if (M.is_diffuse) {
+                // direct light: cast_one_shadow_ray, S/light_samples.py:36-61
+                const double so[3] = {X[0] + eps * n[0], X[1] + eps * n[1], X[2] + eps * n[2]};
+                const lt_point_light lt = P.lights[P.light_choice[base + bounce]];
+                double v[3] = {lt.source[0] - so[0], lt.source[1] - so[1], lt.source[2] - so[2]};
+                const double mag = ::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                const double sd[3] = {v[0] / mag, v[1] / mag, v[2] / mag};
+                int sp; double st;
+                nearest_bvh(tris, nodes, P.n_nodes, so, sd, inf, sp, st);
+                if (st >= mag - eps) {
+                    const double cos_t = dot3(n, sd);
+                    const double nsd[3] = {-sd[0], -sd[1], -sd[2]};
+                    const double cos_p = dot3(lt.normal, nsd);
+                    const double geom = ::fabs(cos_t * cos_p) / (mag * mag);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) L[k] += thr[k] * ((lt.radiance[k] * (M.diffuse[k] * inv_pi)) * geom * lt.total_area);
+                }
+                // indirect: cosine lobe, :63-80
+                double o4[4];
+                cosine_hemi(n, d, r0, r1, o4);
+                if (o4[3] == 0) { mark_unused(P.rand_0, base, bounce + 1, P.D); break; }
+                const double cos_theta = o4[0] * n[0] + o4[1] * n[1] + o4[2] * n[2];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    thr[k] *= (M.diffuse[k] * inv_pi) * cos_theta / o4[3];
+                    o[k] = X[k] + eps * o4[k];
+                    d[k] = o4[k];
+                }
+            } else if (M.is_mirror) {                                   // :82-85
+                double r[3]; reflect(d, n, r);
+#pragma unroll
+                for (int k = 0; k < 3; k++) { o[k] = X[k] + eps * n[k]; d[k] = r[k]; }
+            } else if (M.transmission > 0.0) {                          // :86-119 (kept as written, quirk B5)
+                const double n1 = inside ? M.ior : 1.0, n2 = inside ? 1.0 : M.ior;
+                const double R0 = ((n1 - n2) / (n1 + n2)) * ((n1 - n2) / (n1 + n2));
+                const double theta = dot3(d, n);
+                const double refl_prob = R0 + (1 - R0) * ::pow(1 - ::cos(theta), 5.0);
+                double Nr = M.ior;
+                if (theta > 0) Nr = 1 / Nr;
+                Nr = 1 / Nr;
+                const double cos_theta = -theta;
+                const double rad = 1 - (Nr * Nr) * (1 - cos_theta * cos_theta);
+                if (rad > 0 && r0 > refl_prob) {
+                    const double kk = Nr * cos_theta - ::sqrt(rad);
+                    double tr[3] = {d[0] * Nr + n[0] * kk, d[1] * Nr + n[1] * kk, d[2] * Nr + n[2] * kk};
+                    normalize3(tr);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { o[k] = X[k] - eps * n[k]; d[k] = tr[k]; }
+                } else {
+                    double r[3]; reflect(d, n, r);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { o[k] = X[k] + eps * n[k]; d[k] = r[k]; }
+                }
+            } else break;                                               // :121-123
+            if (bounce > 5) {                                           // russian roulette, :126-132
+                const double rr = ::fmax(0.05, 1 - thr[1]);
+                if (r0 < rr) { mark_unused(P.rand_0, base, bounce + 1, P.D); break; }
+                thr[0] /= 1 - rr; thr[1] /= 1 - rr; thr[2] /= 1 - rr;
+            }
+            bounce++;
+        }
+        color[0] += L[0]; color[1] += L[1]; color[2] += L[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {                                       // :164-166
+        double c = color[k] / (double)P.S;
+        c = c < 0 ? 0.0 : (c > 1 ? 1.0 : c);
+        P.image[(size_t)pix * 3 + k] += 0.25 * c;
+    }
+}
+
+hipError_t launch_render_surface(const RenderParams& P, hipStream_t s)
+{
+    const int n = P.W * P.H;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_render_surface, dim3((n + 63) / 64), dim3(64), 0, s, P);
+    return hipGetLastError();
+}
+
 static inline unsigned nblk(size_t n, unsigned t) { return (unsigned)((n + t - 1) / t); }
 
 hipError_t launch_intersect_rays(const void* tris, const void* nodes, int n_tris, int n_nodes, const double* o,

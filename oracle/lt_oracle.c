@@ -214,3 +214,106 @@ int lto_intersect_rays(const lto_scene* sc, const double* origins, const double*
     release_f64(&W);
     return 0;
 }
+
+
+/* ---- surface path tracer (f2), S/path_tracing_fix1.py ---------------------- */
+static void mark_unused(double* rand_0, size_t base, int from, int D) /* :36-38, :64-66, :128-130 */
+{
+    for (int b = from; b < D; b++) rand_0[base + b] = INFINITY;
+}
+
+int lto_render_surface(const lto_scene* sc, const lt_surface_material* mats, const lt_point_light* lights,
+                       int n_lights, int W, int H, int S, int D, const double camera[3], double f_distance,
+                       const double* xs, const double* ys, double* rand_0, const double* rand_1,
+                       const int32_t* light_choice, double* image)
+{
+    if (!sc || sc->n_tris <= 0 || !mats || !lights || n_lights <= 0) return LT_E_INVALID;
+    world_f64 Wd; prepare_f64(&Wd, sc);
+    const double eps = 1e-6, inv_pi = 0.3183098861837907;
+    for (int i = 0; i < H; i++) for (int j = 0; j < W; j++) {
+        double color[3] = {0, 0, 0};
+        for (int smp = 0; smp < S; smp++) {
+            const size_t base = (((size_t)i * W + j) * S + smp) * (size_t)D;
+            double o[3] = {camera[0], camera[1], camera[2]};
+            const double jit = rand_0[base];                                   /* :156-157 (quirk B6) */
+            double d[3] = {xs[j] + jit / (double)W - o[0], ys[i] + jit / (double)H - o[1], f_distance - o[2]};
+            normalize3_f64(d);
+            double thr[3] = {1, 1, 1}, L[3] = {0, 0, 0};
+            for (int bounce = 0;;) {
+                if (bounce >= D) break;
+                const double r0 = rand_0[base + bounce], r1 = rand_1[base + bounce];
+                int prim; double t;
+                nearest_bvh_f64(Wd.tris, Wd.nodes, sc->n_nodes, o, d, INFINITY, &prim, &t);
+                if (prim < 0) { mark_unused(rand_0, base, bounce, D); break; }
+                const lt_surface_material* M = &mats[prim];
+                double n[3] = {Wd.tris[prim].n[0], Wd.tris[prim].n[1], Wd.tris[prim].n[2]};
+                const double X[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+                if (M->is_light) for (int k = 0; k < 3; k++) L[k] += M->emission * thr[k];
+                int inside = 0;
+                if (dot3_f64(n, d) > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; inside = 1; }
+                if (M->is_diffuse) {
+                    const double so[3] = {X[0] + eps * n[0], X[1] + eps * n[1], X[2] + eps * n[2]};
+                    const lt_point_light* lt = &lights[light_choice[base + bounce]];
+                    double v[3] = {lt->source[0] - so[0], lt->source[1] - so[1], lt->source[2] - so[2]};
+                    const double mag = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                    const double sd[3] = {v[0] / mag, v[1] / mag, v[2] / mag};
+                    int sp; double st;
+                    nearest_bvh_f64(Wd.tris, Wd.nodes, sc->n_nodes, so, sd, INFINITY, &sp, &st);
+                    if (st >= mag - eps) {                                     /* S/light_samples.py:53 */
+                        const double cos_t = dot3_f64(n, sd);
+                        const double nsd[3] = {-sd[0], -sd[1], -sd[2]};
+                        const double cos_p = dot3_f64(lt->normal, nsd);
+                        const double geom = fabs(cos_t * cos_p) / (mag * mag);
+                        for (int k = 0; k < 3; k++)
+                            L[k] += thr[k] * ((lt->radiance[k] * (M->diffuse[k] * inv_pi)) * geom * lt->total_area);
+                    }
+                    double o4[4];
+                    cosine_hemi_f64(n, d, r0, r1, o4);
+                    if (o4[3] == 0) { mark_unused(rand_0, base, bounce + 1, D); break; }
+                    const double cos_theta = o4[0] * n[0] + o4[1] * n[1] + o4[2] * n[2];
+                    for (int k = 0; k < 3; k++) {
+                        thr[k] *= (M->diffuse[k] * inv_pi) * cos_theta / o4[3];
+                        o[k] = X[k] + eps * o4[k];
+                        d[k] = o4[k];
+                    }
+                } else if (M->is_mirror) {
+                    double r[3]; reflect_f64(d, n, r);
+                    for (int k = 0; k < 3; k++) { o[k] = X[k] + eps * n[k]; d[k] = r[k]; }
+                } else if (M->transmission > 0.0) {                            /* :86-119, kept as written */
+                    const double n1 = inside ? M->ior : 1.0, n2 = inside ? 1.0 : M->ior;
+                    const double R0 = ((n1 - n2) / (n1 + n2)) * ((n1 - n2) / (n1 + n2));
+                    const double theta = dot3_f64(d, n);
+                    const double refl_prob = R0 + (1 - R0) * pow(1 - cos(theta), 5.0);
+                    double Nr = M->ior;
+                    if (theta > 0) Nr = 1 / Nr;
+                    Nr = 1 / Nr;
+                    const double cos_theta = -theta;
+                    const double rad = 1 - (Nr * Nr) * (1 - cos_theta * cos_theta);
+                    if (rad > 0 && r0 > refl_prob) {
+                        const double kk = Nr * cos_theta - sqrt(rad);
+                        double tr[3] = {d[0] * Nr + n[0] * kk, d[1] * Nr + n[1] * kk, d[2] * Nr + n[2] * kk};
+                        normalize3_f64(tr);
+                        for (int k = 0; k < 3; k++) { o[k] = X[k] - eps * n[k]; d[k] = tr[k]; }
+                    } else {
+                        double r[3]; reflect_f64(d, n, r);
+                        for (int k = 0; k < 3; k++) { o[k] = X[k] + eps * n[k]; d[k] = r[k]; }
+                    }
+                } else break;
+                if (bounce > 5) {
+                    const double rr = fmax(0.05, 1 - thr[1]);
+                    if (r0 < rr) { mark_unused(rand_0, base, bounce + 1, D); break; }
+                    thr[0] /= 1 - rr; thr[1] /= 1 - rr; thr[2] /= 1 - rr;
+                }
+                bounce++;
+            }
+            color[0] += L[0]; color[1] += L[1]; color[2] += L[2];
+        }
+        for (int k = 0; k < 3; k++) {
+            double c = color[k] / (double)S;
+            c = c < 0 ? 0.0 : (c > 1 ? 1.0 : c);
+            image[((size_t)i * W + j) * 3 + k] += 0.25 * c;
+        }
+    }
+    release_f64(&Wd);
+    return 0;
+}

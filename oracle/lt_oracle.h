@@ -77,6 +77,15 @@ int lto_rng_raw(uint64_t seed, uint64_t photon_id, uint32_t count, uint32_t* out
  * out[n][16] = centroid[3], edge_1[3], edge_2[3], normal[3], num, pad[3] */
 int lto_triangle_fields(const double* tris, size_t n, double* out);
 
+/* Surface path tracer: restates trace_path + render_scene + cast_one_shadow_ray
+ * (S/path_tracing_fix1.py:18-169, S/light_samples.py:36-61) in double precision,
+ * pixels in row-major order.  Nearest hits use the oracle's BVH (== brute force;
+ * the reference traversal's bug B3 is not reproduced).  Pinned by fixture G8. */
+int lto_render_surface(const lto_scene* sc, const lt_surface_material* mats, const lt_point_light* lights,
+                       int n_lights, int width, int height, int samples, int max_depth, const double camera[3],
+                       double f_distance, const double* xs, const double* ys, double* rand_0, const double* rand_1,
+                       const int32_t* light_choice, double* image);
+
 #ifdef __cplusplus
 }
 #endif

@@ -175,6 +175,42 @@ class OracleScene:
         return prim, t
 
 
+class SurfaceMaterial(C.Structure):
+    _fields_ = [("diffuse", C.c_double * 3), ("emission", C.c_double), ("ior", C.c_double),
+                ("transmission", C.c_double), ("is_diffuse", C.c_int32), ("is_mirror", C.c_int32),
+                ("is_light", C.c_int32), ("pad_", C.c_int32)]
+
+
+class PointLight(C.Structure):
+    _fields_ = [("source", C.c_double * 3), ("normal", C.c_double * 3), ("radiance", C.c_double * 3),
+                ("total_area", C.c_double)]
+
+
+def render_surface(scene, mats, lights, camera, f_distance, xs, ys, rand_0, rand_1, light_choice, image):
+    """mats: [T, 9] rows (diffuse[3], emission, ior, transmission, is_diffuse, is_mirror, is_light);
+    lights: [L, 10] rows (source[3], normal[3], radiance[3], total_area).  rand_0 and image updated in place."""
+    s = scene._c()
+    mats = np.asarray(mats, dtype=np.float64); lights = np.asarray(lights, dtype=np.float64)
+    ma = (SurfaceMaterial * len(mats))()
+    for i, r in enumerate(mats):
+        ma[i].diffuse[:] = list(r[:3]); ma[i].emission, ma[i].ior, ma[i].transmission = r[3], r[4], r[5]
+        ma[i].is_diffuse, ma[i].is_mirror, ma[i].is_light = int(r[6]), int(r[7]), int(r[8])
+    la = (PointLight * len(lights))()
+    for i, r in enumerate(lights):
+        la[i].source[:] = list(r[:3]); la[i].normal[:] = list(r[3:6]); la[i].radiance[:] = list(r[6:9]); la[i].total_area = r[9]
+    H, W, S, D = rand_0.shape
+    assert rand_0.dtype == np.float64 and rand_0.flags["C_CONTIGUOUS"] and image.flags["C_CONTIGUOUS"]
+    lc = np.ascontiguousarray(light_choice, dtype=np.int32)
+    r1 = np.ascontiguousarray(rand_1, dtype=np.float64)
+    xs = np.ascontiguousarray(xs, dtype=np.float64); ys = np.ascontiguousarray(ys, dtype=np.float64)
+    cam = (C.c_double * 3)(*[float(x) for x in np.asarray(camera).ravel()[:3]])
+    rc = lib().lto_render_surface(C.byref(s), ma, la, C.c_int(len(lights)), C.c_int(W), C.c_int(H), C.c_int(S), C.c_int(D),
+                                  cam, C.c_double(f_distance), _dp(xs), _dp(ys), _dp(rand_0), _dp(r1), _ip(lc), _dp(image))
+    if rc != 0:
+        raise RuntimeError("lto_render_surface failed: %d" % rc)
+    return image
+
+
 def eval_fn(name, inp):
     fn = FN[name]
     k_in, k_out = _FN_SHAPE[fn]

@@ -375,3 +375,59 @@ def test_large_mesh_in_global_memory(ctx):
     check_counters(c, co, n)
     assert int((fx != fxo).sum()) == 0
     assert c["w_escaped_mesh"] > 0 and fx.sum() > 0
+
+
+# ---------------------------------------------------------------- f2: surface path tracer vs the reference render
+@pytest.mark.parametrize("name", ["glass", "mirror"])
+def test_g8_surface_render(ctx, golden_dir, name):
+    """render_scene (path_tracing_fix1.py:139-169) through lt_render_surface against the image the REFERENCE
+    produced from the same tables (G8), incl. the +inf markers it leaves in rand_0."""
+    from light_transport_amd import _lib
+    g8 = load(golden_dir, "g8_render_fix1.npz")
+    inp = S.g8_inputs(g8, name)
+    m = inp["mesh"]
+    ctx.set_mesh(m["verts"], m["med_front"], m["med_back"], m["nodes"])
+    mats = (_lib.SurfaceMaterial * len(inp["mats"]))()
+    for i, r in enumerate(inp["mats"]):
+        mats[i].diffuse[:] = list(r[:3]); mats[i].emission, mats[i].ior, mats[i].transmission = r[3], r[4], r[5]
+        mats[i].is_diffuse, mats[i].is_mirror, mats[i].is_light = int(r[6]), int(r[7]), int(r[8])
+    lights = (_lib.PointLight * len(inp["lights"]))()
+    for i, r in enumerate(inp["lights"]):
+        lights[i].source[:] = list(r[:3]); lights[i].normal[:] = list(r[3:6]); lights[i].radiance[:] = list(r[6:9])
+        lights[i].total_area = r[9]
+    ctx.set_surface_materials(mats); ctx.set_lights(lights)
+    H, W, _, _ = inp["shape"]
+    img = np.zeros((H, W, 3)); r0 = inp["rand_0"].copy()
+    ctx.render_surface(inp["camera"], inp["f_distance"], inp["xs"], inp["ys"], r0, np.ascontiguousarray(inp["rand_1"]),
+                       inp["light_choice"], img)
+    S.check_g8_image(img, r0, g8, name)
+    # accumulation semantics of :166 (4 calls -> full image): a second call adds the same quarter again
+    r0b = inp["rand_0"].copy()
+    ctx.render_surface(inp["camera"], inp["f_distance"], inp["xs"], inp["ys"], r0b, np.ascontiguousarray(inp["rand_1"]),
+                       inp["light_choice"], img)
+    np.testing.assert_allclose(img, 2 * g8[name + "_brute_image"], rtol=1e-9, atol=1e-12)
+
+
+def test_render_scene_object_api(ctx, golden_dir):
+    """The reference-style call: Scene + primitives + linear BVH -> ndarray."""
+    from light_transport_amd.src import constants as K, cornell_box as cb, bvh_new as B
+    from light_transport_amd.src.material import Material, Color
+    from light_transport_amd.src.light_samples import generate_area_light_samples
+    from light_transport_amd.src.path_tracing_fix1 import render_scene
+    from light_transport_amd.src.scene import Scene
+    depth = 7.5
+    white = Color(np.zeros(3), np.array([0.55, 0.55, 0.55]), np.array([0.7, 0.7, 0.7]))
+    surf = Material(color=white, shininess=30, reflection=0.1, ior=1.521, transmission=1)
+    src = Material(color=K.WHITE, shininess=1, reflection=0.9, ior=1.5, emission=200)
+    lq = cb.get_light_quad(depth, src)
+    objects = cb.get_cornell_box(depth, surf, surf, surf) + cb.get_cone(K.GLASS_MAT) + lq
+    np.random.seed(1)
+    lights = generate_area_light_samples(lq[0], lq[1], src, 40, 4)
+    g8 = load(golden_dir, "g8_render_fix1.npz")
+    np.testing.assert_allclose(np.array([l.source[:3] for l in lights]), g8["glass_lights"][:, :3], atol=1e-15)
+    ordered, linear = B.build_linear_bvh(objects)
+    np.random.seed(0)
+    sc = Scene(camera=np.array([0, 0, depth + 0.5, 1.0]), lights=lights, width=24, height=16, max_depth=6,
+               f_distance=depth, number_of_samples=2)
+    img = render_scene(sc, ordered, linear, ctx=ctx)
+    assert img is sc.image and img.shape == (16, 24, 3) and 0 < img.max() <= 0.25 and np.isinf(sc.rand_0).any()

@@ -128,6 +128,19 @@ def test_g6_triangle_fields(golden_dir):
     np.testing.assert_allclose(f[:, 12], g6["fields"][:, 12], rtol=1e-13, atol=1e-12)  # a cancelling dot product
 
 
+@pytest.mark.parametrize("name", ["glass", "mirror"])
+def test_g8_surface_render(golden_dir, name):
+    """f2: the reference's working product (path_tracing_fix1.render_scene) reproduced by the oracle."""
+    g8 = load(golden_dir, "g8_render_fix1.npz")
+    inp = S.g8_inputs(g8, name)
+    sc = O.OracleScene([(0, 0, 0, 1)], (1, 1, 1), (0, 0, 0), (1, 1, 1), mesh=inp["mesh"])
+    H, W, _, _ = inp["shape"]
+    img = np.zeros((H, W, 3)); r0 = inp["rand_0"].copy()
+    O.render_surface(sc, inp["mats"], inp["lights"], inp["camera"], inp["f_distance"], inp["xs"], inp["ys"], r0,
+                     inp["rand_1"], inp["light_choice"], img)
+    S.check_g8_image(img, r0, g8, name)
+
+
 # ------------------------------------------------------------------ part 2
 def test_xorwow_known_answer():
     """Marsaglia's xorwow with rocRAND's seeding: seed 0 state is the published
