@@ -245,6 +245,30 @@ int lt_render_surface(lt_ctx* ctx, int width, int height, int samples, int max_d
                       const double* ys, double* rand_0, const double* rand_1,
                       const int32_t* light_choice, double* image);
 
+/* ---- light sub-path vertices ("photon map" output) ----- */
+/* Role of the Vertex record and of generate_light_subpaths / random_walk
+ * (vertex.py:24-37, bdpt.py:18-147,258-268; both unrunnable in the reference):
+ * besides depositing into the grid, the walk stores the first
+ * max_vertices_per_photon vertices of every photon's path. */
+#define LT_VERTEX_LIGHT 5        /* emission point (constants.py:22, Medium.LIGHT)     */
+#define LT_VERTEX_REFLECTIVE 3   /* boundary event, reflected (Medium.REFLECTIVE)      */
+#define LT_VERTEX_TRANSMISSIVE 4 /* boundary event, refracted / escaped                */
+#define LT_VERTEX_VOLUME 7       /* interaction site in a medium (no reference value)  */
+typedef struct lt_vertex {
+    double point[3];     /* Vertex.point                                              */
+    double direction[3]; /* direction of travel on arrival                            */
+    double throughput;   /* photon weight on arrival (Vertex.throughput, scalar)      */
+    int32_t kind;        /* LT_VERTEX_* (Vertex.medium)                               */
+    int32_t medium;      /* layer index (slabs) / medium id (meshes) on arrival       */
+    uint32_t step;       /* photon-step index of the event (0 = emission)             */
+    uint32_t pad_;
+} lt_vertex;
+/* 0 disables capture (default).  Applies to subsequent lt_launch calls. */
+int lt_set_vertex_capture(lt_ctx* ctx, uint32_t max_vertices_per_photon);
+/* vertices [n_photons][max_vertices_per_photon] and counts [n_photons] of the
+ * LAST lt_launch (photon index = id - photon_offset); blocking D2H. */
+int lt_read_vertices(lt_ctx* ctx, lt_vertex* vertices_out, uint32_t* counts_out, uint64_t n_photons);
+
 /* device description for bench reports */
 int lt_device_info(lt_ctx* ctx, char* name, size_t name_len, int* n_cus,
                    int* clock_mhz, size_t* hbm_bytes);

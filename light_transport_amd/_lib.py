@@ -27,8 +27,13 @@ SYMBOLS = [
     "lt_last_kernel_ms", "lt_zero_tally", "lt_read_grid", "lt_read_grid_f64", "lt_read_counters",
     "lt_grid_device_ptr", "lt_counters_device_ptr", "lt_stream", "lt_reduce_grid", "lt_intersect_rays",
     "lt_triangle_intersect", "lt_intersect_bounds", "lt_eval", "lt_rng_raw", "lt_device_info",
-    "lt_set_surface_materials", "lt_set_lights", "lt_render_surface",
+    "lt_set_surface_materials", "lt_set_lights", "lt_render_surface", "lt_set_vertex_capture", "lt_read_vertices",
 ]
+
+# lt_vertex as a NumPy record (72 bytes, same layout as the C struct)
+VERTEX_DTYPE = np.dtype([("point", "<f8", 3), ("direction", "<f8", 3), ("throughput", "<f8"), ("kind", "<i4"),
+                         ("medium", "<i4"), ("step", "<u4"), ("pad_", "<u4")])
+VERTEX_LIGHT, VERTEX_REFLECTIVE, VERTEX_TRANSMISSIVE, VERTEX_VOLUME = 5, 3, 4, 7
 
 
 class LtError(RuntimeError):
@@ -309,6 +314,20 @@ class Context:
         out = np.empty((a.shape[0], k_out), dtype=np.float64)
         self._ck(lib().lt_eval(self._h, C.c_int(fn), _dp(a), C.c_size_t(a.shape[0]), _dp(out)), "lt_eval")
         return out
+
+    # -- light sub-path vertices (f4) ----------------------------------------
+    def set_vertex_capture(self, max_vertices_per_photon):
+        self._ck(lib().lt_set_vertex_capture(self._h, C.c_uint32(int(max_vertices_per_photon))), "lt_set_vertex_capture")
+        self._max_vertices = int(max_vertices_per_photon)
+
+    def read_vertices(self, n_photons):
+        """-> (vertices [n_photons, K] record array of VERTEX_DTYPE, counts [n_photons] uint32) of the last launch."""
+        k = getattr(self, "_max_vertices", 0)
+        v = np.zeros((int(n_photons), k), dtype=VERTEX_DTYPE)
+        cnt = np.zeros(int(n_photons), dtype=np.uint32)
+        self._ck(lib().lt_read_vertices(self._h, v.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p),
+                                        C.c_uint64(int(n_photons))), "lt_read_vertices")
+        return v, cnt
 
     # -- surface path tracing (f2) ------------------------------------------
     def set_surface_materials(self, mats):

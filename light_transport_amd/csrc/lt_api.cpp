@@ -70,12 +70,14 @@ struct lt_ctx {
     int src_type = LT_SRC_PENCIL, start_medium = 0;
     double src_pos[3] = {0, 0, 0}, src_dir[3] = {0, 0, 1}, src_extra[6] = {0, 0, 0, 0, 0, 0};
     uint32_t max_steps = 1000000;
+    uint32_t max_vertices = 0;
+    uint64_t captured_photons = 0;
     int blocks_per_cu = 0, threads_per_block = 0;
 
     // device buffers
     DevBuf d_media[2], d_zb[2], d_lm, d_tris[2], d_nodes[2];  // [0]=f64, [1]=f32
     DevBuf d_grid, d_counters, d_head, d_table, d_scratch_in, d_scratch_out, d_scratch_aux;
-    DevBuf d_mats, d_lights, d_r0, d_r1, d_lc, d_img, d_xy;
+    DevBuf d_mats, d_lights, d_r0, d_r1, d_lc, d_img, d_xy, d_vtx, d_vcnt;
     bool tables_dirty = true;
     bool timed = false;
 
@@ -285,7 +287,7 @@ int lt_destroy(lt_ctx* c)
     c->d_lm.release(); c->d_grid.release(); c->d_counters.release(); c->d_head.release(); c->d_table.release();
     c->d_scratch_in.release(); c->d_scratch_out.release(); c->d_scratch_aux.release();
     c->d_mats.release(); c->d_lights.release(); c->d_r0.release(); c->d_r1.release(); c->d_lc.release();
-    c->d_img.release(); c->d_xy.release();
+    c->d_img.release(); c->d_xy.release(); c->d_vtx.release(); c->d_vcnt.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -468,6 +470,16 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     P.table = (const double*)c->d_table.p; P.table_steps = table_steps;
     P.max_steps = c->max_steps;
     P.counters = (DevCounters*)c->d_counters.p;
+    c->captured_photons = 0;
+    if (c->max_vertices > 0) {
+        const size_t vb = (size_t)n_photons * c->max_vertices * sizeof(lt_vertex);
+        if (vb > ((size_t)64 << 30)) return c->fail(LT_E_NOMEM, "lt_launch: vertex capture needs %zu bytes (> 64 GiB)", vb);
+        HIP_TRY(c, c->d_vtx.ensure(vb));
+        HIP_TRY(c, c->d_vcnt.ensure((size_t)n_photons * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemsetAsync(c->d_vcnt.p, 0, (size_t)n_photons * sizeof(uint32_t), c->stream));
+        P.vertices = (lt_vertex*)c->d_vtx.p; P.vertex_counts = (uint32_t*)c->d_vcnt.p; P.max_vertices = c->max_vertices;
+        c->captured_photons = n_photons;
+    }
 
     LaunchCfg cfg;
     cfg.threads = c->threads_per_block > 0 ? c->threads_per_block : 256;
@@ -733,6 +745,27 @@ int lt_rng_raw(lt_ctx* c, uint64_t seed, uint64_t photon_id, uint32_t count, uin
     HIP_TRY(c, c->d_scratch_aux.ensure((size_t)count * 4));
     HIP_TRY(c, launch_rng_raw(seed, photon_id, count, (uint32_t*)c->d_scratch_aux.p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch_aux.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_set_vertex_capture(lt_ctx* c, uint32_t max_vertices_per_photon)
+{
+    CHECK_CTX(c);
+    if (max_vertices_per_photon > 4096) return c->fail(LT_E_INVALID, "lt_set_vertex_capture: at most 4096 vertices per photon");
+    c->max_vertices = max_vertices_per_photon;
+    return LT_OK;
+}
+
+int lt_read_vertices(lt_ctx* c, lt_vertex* vertices_out, uint32_t* counts_out, uint64_t n_photons)
+{
+    CHECK_CTX(c);
+    if (c->captured_photons == 0 || c->max_vertices == 0) return c->fail(LT_E_STATE, "lt_read_vertices: the last launch captured nothing");
+    if (!vertices_out || !counts_out || n_photons != c->captured_photons)
+        return c->fail(LT_E_INVALID, "lt_read_vertices: expected buffers for %llu photons", (unsigned long long)c->captured_photons);
+    BIND(c);
+    HIP_TRY(c, hipMemcpyAsync(counts_out, c->d_vcnt.p, (size_t)n_photons * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(vertices_out, c->d_vtx.p, (size_t)n_photons * c->max_vertices * sizeof(lt_vertex), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return LT_OK;
 }

@@ -64,6 +64,10 @@ struct WalkParams {
     unsigned long long table_steps;
     unsigned max_steps;
     DevCounters* counters;
+    // light sub-path capture (null = off)
+    lt_vertex* vertices;
+    uint32_t* vertex_counts;
+    unsigned max_vertices;
 };
 
 struct LaunchCfg {

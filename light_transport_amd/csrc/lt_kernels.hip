@@ -367,6 +367,21 @@ template <typename T> LT_DEV T wave_sum(T v)
     return v;
 }
 
+// light sub-path capture (f4): store vertex k of photon `rel` while k < max_vertices
+template <typename R>
+LT_DEV void record_vertex(const WalkParams& P, unsigned long long rel, unsigned& nv, R px, R py, R pz, R ux, R uy,
+                          R uz, R w, int kind, int medium, unsigned step)
+{
+    if (nv < P.max_vertices) {
+        lt_vertex* v = P.vertices + rel * (unsigned long long)P.max_vertices + nv;
+        v->point[0] = (double)px; v->point[1] = (double)py; v->point[2] = (double)pz;
+        v->direction[0] = (double)ux; v->direction[1] = (double)uy; v->direction[2] = (double)uz;
+        v->throughput = (double)w; v->kind = kind; v->medium = medium; v->step = step; v->pad_ = 0;
+        nv++;
+        P.vertex_counts[rel] = nv;
+    }
+}
+
 constexpr unsigned kPacket = 64;  // photon ids taken from the global queue per atomic
 
 // ---------------------------------------------------------------------------
@@ -408,7 +423,7 @@ __global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
     bool alive = false;
     R px = 0, py = 0, pz = 0, ux = 0, uy = 0, uz = 1, w = 0, sleft = 0;
     int cur = 0;
-    unsigned step = 0, max_steps = P.max_steps;
+    unsigned step = 0, max_steps = P.max_steps, nv = 0;
     unsigned long long pid = 0, grp = 0;
     rocrand_state_xorwow rng;
     // per-lane accumulators of the frequent events
@@ -510,6 +525,11 @@ __global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
                 } else {
                     cur = P.start_medium;
                 }
+                nv = 0;
+                if (P.vertices) {
+                    P.vertex_counts[id] = 0;
+                    if (alive) record_vertex<R>(P, id, nv, px, py, pz, ux, uy, uz, w, LT_VERTEX_LIGHT, cur, 0u);
+                }
                 if constexpr (TABLE) {
                     unsigned long long cap = P.table_steps > grp ? P.table_steps - grp : 0ull;
                     if (cap < (unsigned long long)max_steps) max_steps = (unsigned)cap;
@@ -578,6 +598,9 @@ __global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
                     }
                     R d[3] = {ux, uy, uz}, ct, refr[3];
                     R Rf = boundary(d, nf, n1, n2, &ct, refr);
+                    if (P.vertices)
+                        record_vertex<R>(P, pid - P.photon_offset, nv, px, py, pz, ux, uy, uz, w,
+                                         (u4[3] <= Rf) ? LT_VERTEX_REFLECTIVE : LT_VERTEX_TRANSMISSIVE, cur, step);
                     if (u4[3] <= Rf) {  // reflect: S/brdf.py:8-9
                         R ro[3]; reflect(d, nf, ro);
                         ux = ro[0]; uy = ro[1]; uz = ro[2];
@@ -597,6 +620,8 @@ __global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
                     // ---- interaction site: move, drop, spin, roulette ----
                     px += ux * s; py += uy * s; pz += uz * s;
                     sleft = 0;
+                    if (P.vertices)
+                        record_vertex<R>(P, pid - P.photon_offset, nv, px, py, pz, ux, uy, uz, w, LT_VERTEX_VOLUME, cur, step);
                     const R dw = w * Mp->absorb;
                     const R fx = (px - gx0) * ivx, fy = (py - gy0) * ivy, fz = (pz - gz0) * ivz;
                     if (fx >= 0 && fx < fnx && fy >= 0 && fy < fny && fz >= 0 && fz < fnz) {

@@ -155,6 +155,22 @@ class PhotonTracer:
         return self.ctx.last_kernel_ms()
 
 
+def generate_light_subpaths(tracer, n_photons, max_depth, seed=0, photon_offset=0, as_objects=False):
+    """Role of generate_light_subpaths (bdpt.py:258-268): trace ``n_photons`` from the configured source and return
+    the first ``max_depth`` vertices of every path.  Returns (records [n, max_depth], counts [n]); with
+    ``as_objects`` a list of lists of ``Vertex``.  The grid tally is accumulated as in a normal run."""
+    tracer.ctx.set_vertex_capture(max_depth)
+    try:
+        tracer.run(n_photons, seed=seed, photon_offset=photon_offset)
+        rec, cnt = tracer.ctx.read_vertices(n_photons)
+    finally:
+        tracer.ctx.set_vertex_capture(0)
+    if not as_objects:
+        return rec, cnt
+    from .vertex import Vertex
+    return [[Vertex.from_record(rec[i, k]) for k in range(int(cnt[i]))] for i in range(int(n_photons))]
+
+
 def fluence(absorbed, mu_a, voxel_volume, n_photons):
     """Host post-step (Appendix C.4): fluence = absorbed / (mu_a * dV * N)."""
     return np.asarray(absorbed, dtype=np.float64) / (float(mu_a) * float(voxel_volume) * float(n_photons))

@@ -136,8 +136,18 @@ int lto_run(const lto_scene* sc, uint64_t n_photons, uint64_t photon_offset, uin
     if ((sc->n_layers > 0) == (sc->n_tris > 0)) return LT_E_INVALID;
     if (walk_f32 && rng_table) return LT_E_UNSUPPORTED;
     return walk_f32
-        ? run_f32(sc, n_photons, photon_offset, seed, rng_table, table_steps, grid_f64, grid_fx, counters, n_threads)
-        : run_f64(sc, n_photons, photon_offset, seed, rng_table, table_steps, grid_f64, grid_fx, counters, n_threads);
+        ? run_f32(sc, n_photons, photon_offset, seed, rng_table, table_steps, grid_f64, grid_fx, counters, n_threads, NULL, NULL, 0)
+        : run_f64(sc, n_photons, photon_offset, seed, rng_table, table_steps, grid_f64, grid_fx, counters, n_threads, NULL, NULL, 0);
+}
+
+/* f4: the same walk, also storing the first max_vertices vertices of every path */
+int lto_run_capture(const lto_scene* sc, uint64_t n_photons, uint64_t photon_offset, uint64_t seed,
+                    double* grid_f64, lt_counters* counters, lt_vertex* vertices, uint32_t* counts,
+                    uint32_t max_vertices)
+{
+    if (!sc || !counters || !vertices || !counts || max_vertices == 0) return LT_E_INVALID;
+    if ((sc->n_layers > 0) == (sc->n_tris > 0)) return LT_E_INVALID;
+    return run_f64(sc, n_photons, photon_offset, seed, NULL, 0, grid_f64, NULL, counters, 1, vertices, counts, max_vertices);
 }
 
 int lto_rng_raw(uint64_t seed, uint64_t photon_id, uint32_t count, uint32_t* out)

@@ -62,6 +62,10 @@ int lto_run(const lto_scene* sc, uint64_t n_photons, uint64_t photon_offset,
             int walk_f32, double* grid_f64, uint64_t* grid_fx,
             lt_counters* counters, int n_threads);
 
+int lto_run_capture(const lto_scene* sc, uint64_t n_photons, uint64_t photon_offset, uint64_t seed,
+                    double* grid_f64, lt_counters* counters, lt_vertex* vertices, uint32_t* counts,
+                    uint32_t max_vertices);
+
 /* unit functions (double precision), same meaning as lt_eval / lt_* queries */
 int lto_eval(int fn, const double* in, size_t n, double* out);
 int lto_triangle_intersect(const double* origins, const double* dirs,

@@ -17,6 +17,8 @@ _LIB = None
 FN = dict(HG_PDF=0, HG_SAMPLE=1, ONB=2, DISK=3, COSINE_HEMI=4, REFLECT=5, BOUNDARY=6, SPIN=7)
 _FN_SHAPE = {0: (2, 1), 1: (2, 1), 2: (3, 6), 3: (2, 2), 4: (8, 4), 5: (6, 3), 6: (8, 5), 7: (5, 3)}
 FX_SCALE = 2.0 ** 40
+VERTEX_DTYPE = np.dtype([("point", "<f8", 3), ("direction", "<f8", 3), ("throughput", "<f8"), ("kind", "<i4"),
+                         ("medium", "<i4"), ("step", "<u4"), ("pad_", "<u4")])
 
 
 class Medium(C.Structure):
@@ -159,6 +161,20 @@ class OracleScene:
         shape = (self.nz, self.ny, self.nx)
         return (g64.reshape(shape) if g64 is not None else None,
                 gfx.reshape(shape) if gfx is not None else None, cnt.as_dict())
+
+    def run_capture(self, n_photons, max_vertices, seed=0, photon_offset=0):
+        """f4: (grid, counters, vertices [n, K] records, counts [n]) with the light sub-path vertices stored."""
+        s = self._c()
+        g64 = np.zeros(self.nx * self.ny * self.nz, dtype=np.float64)
+        v = np.zeros((n_photons, max_vertices), dtype=VERTEX_DTYPE)
+        cnt = np.zeros(n_photons, dtype=np.uint32)
+        c = Counters()
+        rc = lib().lto_run_capture(C.byref(s), C.c_uint64(n_photons), C.c_uint64(photon_offset), C.c_uint64(seed),
+                                   _dp(g64), C.byref(c), v.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p),
+                                   C.c_uint32(max_vertices))
+        if rc != 0:
+            raise RuntimeError("lto_run_capture failed: %d" % rc)
+        return g64.reshape(self.nz, self.ny, self.nx), c.as_dict(), v, cnt
 
     def intersect_rays(self, origins, dirs, tmax=None, use_bvh=True):
         s = self._c()

@@ -431,3 +431,41 @@ def test_render_scene_object_api(ctx, golden_dir):
                f_distance=depth, number_of_samples=2)
     img = render_scene(sc, ordered, linear, ctx=ctx)
     assert img is sc.image and img.shape == (16, 24, 3) and 0 < img.max() <= 0.25 and np.isinf(sc.rand_0).any()
+
+
+# ---------------------------------------------------------------- f4: light sub-path vertices
+@pytest.mark.parametrize("name", ["two_layer", "cornell"])
+def test_light_subpath_vertices(ctx, name):
+    """The walk stores the first K vertices of every path (role of random_walk / Vertex, bdpt.py:18-147,
+    vertex.py:24-37); records must equal the oracle's, and capture must not disturb the tally."""
+    prob = dict(two_layer=S.two_layer(n=32), cornell=S.cornell(32))[name]
+    n, K = 3000, 12
+    prob.apply(ctx, "f64")
+    ctx.set_vertex_capture(K)
+    ctx.launch(n, seed=31); ctx.sync()
+    g, c = ctx.read_grid(), ctx.read_counters()
+    v, cnt = ctx.read_vertices(n)
+    ctx.set_vertex_capture(0)
+    go, co, vo, cnto = prob.oracle().run_capture(n, K, seed=31)
+    check_counters(c, co, n)
+    S.assert_grid_close(g, go)
+    np.testing.assert_array_equal(cnt, cnto)
+    assert cnt.max() == K and cnt.min() >= 1
+    live = np.arange(K)[None, :] < cnt[:, None]
+    for f in ("kind", "medium", "step"):
+        np.testing.assert_array_equal(v[f][live], vo[f][live])
+    np.testing.assert_allclose(v["point"][live], vo["point"][live], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(v["direction"][live], vo["direction"][live], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(v["throughput"][live], vo["throughput"][live], rtol=1e-12)
+    from light_transport_amd import _lib
+    assert np.all(v["kind"][:, 0] == _lib.VERTEX_LIGHT) and np.all(v["step"][:, 0] == 0)
+    kinds = set(np.unique(v["kind"][live]))
+    assert _lib.VERTEX_VOLUME in kinds and (_lib.VERTEX_TRANSMISSIVE in kinds or _lib.VERTEX_REFLECTIVE in kinds)
+    # object form
+    from light_transport_amd.src import photon_tracing as PT
+    tr = PT.PhotonTracer(ctx=ctx)
+    paths = PT.generate_light_subpaths(tr, 50, 5, seed=31, as_objects=True)
+    assert len(paths) == 50 and all(1 <= len(p) <= 5 for p in paths) and paths[0][0].hit_light
+    np.testing.assert_allclose(paths[7][1].point, v["point"][7, 1], atol=1e-12)
+    with pytest.raises(Exception):
+        ctx.read_vertices(n)       # nothing captured by the last launch
