@@ -133,6 +133,17 @@ int lt_set_max_steps(lt_ctx* ctx, uint32_t max_steps);
  * (multiples of 64).  0 keeps the default. */
 int lt_set_launch_config(lt_ctx* ctx, int blocks_per_cu, int threads_per_block);
 
+/* how deposits reach the grid.  LT_MODE_ATOMIC: one no-return global atomic per
+ * deposit record.  LT_MODE_LOG: the walk appends records to a coalesced log in
+ * HBM which is radix-partitioned by grid tile and reduced tile by tile in LDS
+ * (no global atomics); photons are traced in batches sized to log_bytes
+ * (0 keeps the current budget; default: a quarter of the device memory, at most 64 GiB).  Results are identical for the
+ * u64 fixed-point tally and equal up to summation order for float tallies.
+ * Table RNG, vertex capture and grids beyond 2^28 voxels use the atomic path. */
+#define LT_MODE_ATOMIC 0
+#define LT_MODE_LOG 1
+int lt_set_tally_mode(lt_ctx* ctx, int mode, uint64_t log_bytes);
+
 /* ---- run --------------------------------------------------------------- */
 /* role of render_scene (path_tracing_fix1.py:139-169): trace photons
  * [photon_offset, photon_offset + n_photons) asynchronously on the ctx stream,

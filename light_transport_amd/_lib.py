@@ -28,6 +28,7 @@ SYMBOLS = [
     "lt_grid_device_ptr", "lt_counters_device_ptr", "lt_stream", "lt_reduce_grid", "lt_intersect_rays",
     "lt_triangle_intersect", "lt_intersect_bounds", "lt_eval", "lt_rng_raw", "lt_device_info",
     "lt_set_surface_materials", "lt_set_lights", "lt_render_surface", "lt_set_vertex_capture", "lt_read_vertices",
+    "lt_set_tally_mode",
 ]
 
 # lt_vertex as a NumPy record (72 bytes, same layout as the C struct)
@@ -219,6 +220,11 @@ class Context:
     def set_launch_config(self, blocks_per_cu=0, threads_per_block=0):
         self._ck(lib().lt_set_launch_config(self._h, C.c_int(blocks_per_cu), C.c_int(threads_per_block)),
                  "lt_set_launch_config")
+
+    def set_tally_mode(self, mode="atomic", log_bytes=0):
+        """'atomic': global atomics per deposit; 'log': deposit log + tile partition + LDS reduce."""
+        m = {"atomic": 0, "log": 1}[mode] if isinstance(mode, str) else int(mode)
+        self._ck(lib().lt_set_tally_mode(self._h, C.c_int(m), C.c_uint64(int(log_bytes))), "lt_set_tally_mode")
 
     # -- run --------------------------------------------------------------
     def launch(self, n_photons, seed=0, photon_offset=0, rng_table=None, f32_walk=False):

@@ -71,6 +71,12 @@ struct lt_ctx {
     double src_pos[3] = {0, 0, 0}, src_dir[3] = {0, 0, 1}, src_extra[6] = {0, 0, 0, 0, 0, 0};
     uint32_t max_steps = 1000000;
     uint32_t max_vertices = 0;
+    int tally_mode = 1;                 // 0: global atomics, 1: deposit log + partition + tile reduce (default)
+    size_t log_budget = (size_t)16 << 30; // bytes for the log and its ping-pong copy
+    double rec_per_photon = 0.0;        // measured deposit records per photon (sizes the batches)
+    size_t log_alloc_records = 0;       // capacity of the log buffers currently allocated
+    int log_alloc_elem = 0;
+    double last_stage_ms[6] = {0, 0, 0, 0, 0, 0};
     uint64_t captured_photons = 0;
     int blocks_per_cu = 0, threads_per_block = 0;
 
@@ -78,6 +84,7 @@ struct lt_ctx {
     DevBuf d_media[2], d_zb[2], d_lm, d_tris[2], d_nodes[2];  // [0]=f64, [1]=f32
     DevBuf d_grid, d_counters, d_head, d_table, d_scratch_in, d_scratch_out, d_scratch_aux;
     DevBuf d_mats, d_lights, d_r0, d_r1, d_lc, d_img, d_xy, d_vtx, d_vcnt;
+    DevBuf d_log_idx, d_log_val, d_tmp_idx, d_tmp_val, d_log_fill, d_log_meta, d_hist, d_tile_base, d_cursor1, d_cursor2, d_items2, d_items_r;
     bool tables_dirty = true;
     bool timed = false;
 
@@ -263,6 +270,10 @@ int lt_create(lt_ctx** out, int device_id)
         delete c;
         return LT_E_UNSUPPORTED;
     }
+    if (e == hipSuccess) {
+        size_t quarter = c->prop.totalGlobalMem / 4;
+        c->log_budget = quarter < ((size_t)64 << 30) ? quarter : ((size_t)64 << 30);
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -288,6 +299,9 @@ int lt_destroy(lt_ctx* c)
     c->d_scratch_in.release(); c->d_scratch_out.release(); c->d_scratch_aux.release();
     c->d_mats.release(); c->d_lights.release(); c->d_r0.release(); c->d_r1.release(); c->d_lc.release();
     c->d_img.release(); c->d_xy.release(); c->d_vtx.release(); c->d_vcnt.release();
+    c->d_log_idx.release(); c->d_log_val.release(); c->d_tmp_idx.release(); c->d_tmp_val.release(); c->d_log_fill.release();
+    c->d_log_meta.release(); c->d_hist.release(); c->d_tile_base.release(); c->d_cursor1.release(); c->d_cursor2.release();
+    c->d_items2.release(); c->d_items_r.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -305,6 +319,7 @@ int lt_set_media(lt_ctx* c, const lt_medium* media, int n)
             return c->fail(LT_E_INVALID, "lt_set_media: medium %d out of range (mu_a,mu_s >= 0, |g| < 1, n > 0)", i);
     }
     c->media.assign(media, media + n);
+    c->rec_per_photon = 0.0;
     c->tables_dirty = true;
     return LT_OK;
 }
@@ -499,11 +514,160 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     cfg.blocks = (int)(want < cap ? want : cap);
     if (cfg.blocks < 1) cfg.blocks = 1;
 
+    // ---- log-structured tally: walk -> deposit log -> partition by grid tile -> LDS tile reduce, in batches
+    const uint32_t n_tiles = (uint32_t)((c->n_vox() + kTileSize - 1) >> kTileShift);
+    const bool use_log = c->tally_mode == 1 && !v.table && c->max_vertices == 0 && n_tiles <= 16384 && !std::getenv("LT_DIAG_NO_TALLY");
+    if (use_log) {
+        const size_t rec_bytes = 4 + c->grid_elem();
+        size_t budget_records = c->log_budget / (2 * rec_bytes);
+        if (budget_records > 0xFFF00000ull) budget_records = 0xFFF00000ull;   // 32-bit record offsets
+        if (budget_records < 64 * (size_t)kLogChunk) return c->fail(LT_E_INVALID, "lt_launch: log budget too small (%zu bytes)", c->log_budget);
+        // size the log to the job: measured records per photon when known, else a pilot-sized log
+        // (a log that turns out too small only diverts the excess deposits to atomics)
+        auto size_log = [&](uint64_t photons_left) -> size_t {
+            double need = c->rec_per_photon > 0.0 ? 1.25 * c->rec_per_photon * (double)photons_left + 1048576.0
+                                                  : 64.0 * 1048576.0;
+            size_t r = need < (double)budget_records ? (size_t)need : budget_records;
+            return ((r + kLogChunk - 1) / kLogChunk) * kLogChunk;
+        };
+        size_t cap_records = size_log(n_photons);
+        uint32_t cap_chunks = (uint32_t)(cap_records / kLogChunk);
+        auto ensure_log = [&]() -> hipError_t {
+            hipError_t e;
+            if (c->log_alloc_elem != (int)c->grid_elem()) c->log_alloc_records = 0;
+            if (cap_records <= c->log_alloc_records) {   // use everything that is already there
+                cap_records = c->log_alloc_records; cap_chunks = (uint32_t)(cap_records / kLogChunk);
+                return hipSuccess;
+            }
+            // grow geometrically so that run-to-run jitter of the record rate does not re-allocate tens of GB
+            size_t grown = cap_records + cap_records / 8;
+            if (grown > budget_records) grown = budget_records;
+            cap_records = (grown / kLogChunk) * kLogChunk; cap_chunks = (uint32_t)(cap_records / kLogChunk);
+            c->log_alloc_records = cap_records; c->log_alloc_elem = (int)c->grid_elem();
+            if ((e = c->d_log_idx.ensure(cap_records * 4)) != hipSuccess) return e;
+            if ((e = c->d_tmp_idx.ensure(cap_records * 4)) != hipSuccess) return e;
+            if ((e = c->d_log_val.ensure(cap_records * c->grid_elem())) != hipSuccess) return e;
+            if ((e = c->d_tmp_val.ensure(cap_records * c->grid_elem())) != hipSuccess) return e;
+            return c->d_log_fill.ensure((size_t)cap_chunks * 4);
+        };
+        HIP_TRY(c, ensure_log());
+        HIP_TRY(c, c->d_log_meta.ensure(64));
+        uint32_t bits2 = 1; while ((1u << (2 * bits2)) < n_tiles) bits2++;
+        const uint32_t nb1 = (n_tiles + (1u << bits2) - 1) >> bits2;
+        HIP_TRY(c, c->d_hist.ensure((size_t)n_tiles * 4)); HIP_TRY(c, c->d_tile_base.ensure((size_t)(n_tiles + 1) * 4));
+        HIP_TRY(c, c->d_cursor1.ensure((size_t)nb1 * 4)); HIP_TRY(c, c->d_cursor2.ensure((size_t)n_tiles * 4));
+        HIP_TRY(c, c->d_items2.ensure((size_t)(nb1 + 1) * 4)); HIP_TRY(c, c->d_items_r.ensure((size_t)(n_tiles + 1) * 4));
+        uint32_t* meta = (uint32_t*)c->d_log_meta.p;   // [0] next chunk, [2..3] totals
+        P.log_idx = (uint32_t*)c->d_log_idx.p; P.log_val = c->d_log_val.p; P.log_fill = (uint32_t*)c->d_log_fill.p;
+        P.log_next = meta; P.log_cap_chunks = cap_chunks;
+        LogReduceParams L;
+        std::memset(&L, 0, sizeof L);
+        L.log_idx = P.log_idx; L.log_val = P.log_val; L.log_fill = P.log_fill;
+        L.tmp_idx = (uint32_t*)c->d_tmp_idx.p; L.tmp_val = c->d_tmp_val.p;
+        L.hist = (uint32_t*)c->d_hist.p; L.tile_base = (uint32_t*)c->d_tile_base.p;
+        L.cursor1 = (uint32_t*)c->d_cursor1.p; L.cursor2 = (uint32_t*)c->d_cursor2.p; L.items2 = (uint32_t*)c->d_items2.p; L.items_r = (uint32_t*)c->d_items_r.p;
+        L.totals = meta + 2; L.n_tiles = n_tiles; L.bits2 = bits2;
+        L.grid = c->d_grid.p; L.n_vox = c->n_vox(); L.tally = c->tally;
+
+        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        uint64_t done = 0;
+        const bool diag = std::getenv("LT_LOG_TIMING") != nullptr;   // per-stage device times (adds syncs)
+        hipEvent_t te[8];
+        double stage[6] = {0, 0, 0, 0, 0, 0};
+        if (diag) for (auto& e : te) HIP_TRY(c, hipEventCreate(&e));
+        int n_batches = 0;
+        while (done < n_photons) {
+            uint64_t batch = n_photons - done;
+            if (c->rec_per_photon <= 0.0) { if (batch > 65536) batch = 65536; }          // pilot batch measures the record rate
+            else {
+                const double fit = 0.8 * (double)cap_records / c->rec_per_photon;
+                if ((double)batch > fit) batch = fit < 4096.0 ? 4096 : (uint64_t)fit;
+            }
+            if (done > 0) {   // re-size with the measured record rate (buffers only ever grow)
+                const size_t want_records = size_log(n_photons - done);
+                if (want_records > cap_records) {
+                    cap_records = want_records; cap_chunks = (uint32_t)(cap_records / kLogChunk);
+                    HIP_TRY(c, ensure_log());
+                    P.log_idx = (uint32_t*)c->d_log_idx.p; P.log_val = c->d_log_val.p; P.log_fill = (uint32_t*)c->d_log_fill.p;
+                    P.log_cap_chunks = cap_chunks;
+                    L.log_idx = P.log_idx; L.log_val = P.log_val; L.log_fill = P.log_fill;
+                    L.tmp_idx = (uint32_t*)c->d_tmp_idx.p; L.tmp_val = c->d_tmp_val.p;
+                }
+            }
+            P.n_photons = batch; P.photon_offset = photon_offset + done;
+            want = (batch + (unsigned long long)cfg.threads - 1) / (unsigned long long)cfg.threads;
+            cfg.blocks = (int)(want < cap ? want : cap);
+            if (cfg.blocks < 1) cfg.blocks = 1;
+            HIP_TRY(c, hipMemsetAsync(c->d_head.p, 0, sizeof(unsigned long long), c->stream));
+            HIP_TRY(c, hipMemsetAsync(meta, 0, 32, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->d_hist.p, 0, (size_t)n_tiles * 4, c->stream));
+            if (diag) HIP_TRY(c, hipEventRecord(te[0], c->stream));
+            HIP_TRY(c, launch_walk(P, v, cfg, c->stream));
+            if (diag) HIP_TRY(c, hipEventRecord(te[7], c->stream));
+            uint32_t h[5] = {0, 0, 0, 0, 0};
+            HIP_TRY(c, hipMemcpyAsync(h, meta, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const bool overflow = h[0] > cap_chunks;
+            L.n_chunks = h[0] < cap_chunks ? h[0] : cap_chunks;
+            if (diag) HIP_TRY(c, hipEventRecord(te[1], c->stream));
+            HIP_TRY(c, launch_log_hist(L, c->stream));
+            if (diag) HIP_TRY(c, hipEventRecord(te[2], c->stream));
+            HIP_TRY(c, launch_log_scan(L, c->stream));
+            if (diag) HIP_TRY(c, hipEventRecord(te[3], c->stream));
+            HIP_TRY(c, hipMemcpyAsync(h + 2, meta + 2, 12, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (diag) HIP_TRY(c, hipEventRecord(te[3], c->stream));
+            HIP_TRY(c, launch_log_part1(L, c->stream));
+            if (diag) HIP_TRY(c, hipEventRecord(te[4], c->stream));
+            HIP_TRY(c, launch_log_part2(L, h[3], c->stream));
+            if (diag) HIP_TRY(c, hipEventRecord(te[5], c->stream));
+            HIP_TRY(c, launch_log_reduce(L, h[4], c->stream));
+            if (diag) {
+                HIP_TRY(c, hipEventRecord(te[6], c->stream));
+                HIP_TRY(c, hipEventSynchronize(te[6]));
+                // te[1] and te[3] were re-recorded after the host syncs, so hist and part1 exclude the sync gaps
+                float f;
+                (void)hipEventElapsedTime(&f, te[0], te[7]); stage[0] += f;
+                (void)hipEventElapsedTime(&f, te[1], te[2]); stage[1] += f;
+                (void)hipEventElapsedTime(&f, te[2], te[3]); stage[2] += f;
+                (void)hipEventElapsedTime(&f, te[3], te[4]); stage[3] += f;
+                (void)hipEventElapsedTime(&f, te[4], te[5]); stage[4] += f;
+                (void)hipEventElapsedTime(&f, te[5], te[6]); stage[5] += f;
+                std::fprintf(stderr, "[lt log] batch %d: %llu photons, %u chunks, %u records (%.1f / photon), %u pass-2 items%s\n",
+                             n_batches, (unsigned long long)batch, L.n_chunks, h[2], (double)h[2] / (double)batch, h[3],
+                             overflow ? ", LOG OVERFLOW -> atomics" : "");
+            }
+            n_batches++;
+            double rate = (double)h[2] / (double)batch;
+            if (overflow) rate *= 1.5;   // part of the batch went through atomics: the true rate is higher
+            c->rec_per_photon = rate > c->rec_per_photon ? rate : 0.5 * (rate + c->rec_per_photon);
+            done += batch;
+        }
+        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        if (diag) {
+            std::fprintf(stderr, "[lt log] stages ms: walk %.2f hist %.2f scan %.2f part1 %.2f part2 %.2f reduce %.2f\n",
+                         stage[0], stage[1], stage[2], stage[3], stage[4], stage[5]);
+            for (auto& e : te) (void)hipEventDestroy(e);
+        }
+        c->timed = true;
+        return LT_OK;
+    }
+
     HIP_TRY(c, hipMemsetAsync(c->d_head.p, 0, sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, launch_walk(P, v, cfg, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
+    return LT_OK;
+}
+
+int lt_set_tally_mode(lt_ctx* c, int mode, uint64_t log_bytes)
+{
+    CHECK_CTX(c);
+    if (mode != 0 && mode != 1) return c->fail(LT_E_INVALID, "lt_set_tally_mode: mode must be LT_MODE_ATOMIC or LT_MODE_LOG");
+    c->tally_mode = mode;
+    if (log_bytes) c->log_budget = (size_t)log_bytes;
+    c->rec_per_photon = 0.0;
     return LT_OK;
 }
 

@@ -38,6 +38,9 @@ struct DevCounters {
 enum { CW_ABSORBED = 0, CW_LOST, CW_ESC_TOP, CW_ESC_BOT, CW_ESC_MESH, CW_SPECULAR, CW_ROULETTE, CW_CAPPED };
 
 constexpr int kMaxMedia = 32;
+constexpr uint32_t kLogChunk = 4096;    // records per log chunk = records per partition work item
+constexpr uint32_t kTileShift = 14;     // grid tile = 16384 consecutive voxels (128 KiB of f64 in LDS)
+constexpr uint32_t kTileSize = 1u << kTileShift;
 constexpr int kMaxLayers = 64;
 
 struct WalkParams {
@@ -64,6 +67,13 @@ struct WalkParams {
     unsigned long long table_steps;
     unsigned max_steps;
     DevCounters* counters;
+    // log-structured tally (null = deposit with global atomics): coalesced deposit log written by the walk,
+    // reduced into the grid by the partition / tile-reduce kernels
+    uint32_t* log_idx;    // [log_cap_chunks * kLogChunk] voxel index
+    void* log_val;        // [log_cap_chunks * kLogChunk] value in the tally's type
+    uint32_t* log_fill;   // [log_cap_chunks] valid records per chunk
+    uint32_t* log_next;   // next free chunk
+    uint32_t log_cap_chunks;
     // light sub-path capture (null = off)
     lt_vertex* vertices;
     uint32_t* vertex_counts;
@@ -104,6 +114,26 @@ struct RenderParams {
     double* image;
 };
 hipError_t launch_render_surface(const RenderParams& P, hipStream_t s);
+
+// log-structured tally pipeline (all on stream s)
+struct LogReduceParams {
+    const uint32_t* log_idx; const void* log_val; const uint32_t* log_fill; uint32_t n_chunks;   // walk output
+    uint32_t* tmp_idx; void* tmp_val;          // ping-pong buffers, same capacity as the log
+    uint32_t* hist;                            // [n_tiles]
+    uint32_t* tile_base;                       // [n_tiles + 1]
+    uint32_t* cursor1;                         // [nb1]
+    uint32_t* cursor2;                         // [n_tiles]
+    uint32_t* items2;                          // [nb1 + 1] prefix of pass-2 work items per level-1 bin
+    uint32_t* items_r;                         // [n_tiles + 1] prefix of reduce work items per tile
+    uint32_t* totals;                          // [3]: total records, pass-2 items, reduce items
+    uint32_t n_tiles, bits2;                   // level-2 digit width; level-1 bins = ceil(n_tiles >> bits2)
+    void* grid; size_t n_vox; int tally;
+};
+hipError_t launch_log_hist(const LogReduceParams& L, hipStream_t s);
+hipError_t launch_log_scan(const LogReduceParams& L, hipStream_t s);
+hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s);
+hipError_t launch_log_part2(const LogReduceParams& L, uint32_t n_items, hipStream_t s);
+hipError_t launch_log_reduce(const LogReduceParams& L, uint32_t n_items, hipStream_t s);
 
 hipError_t launch_intersect_rays(const void* tris, const void* nodes, int n_tris, int n_nodes,
                                  const double* o, const double* d, const double* tmax, size_t n,

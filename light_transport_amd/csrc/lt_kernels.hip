@@ -382,13 +382,58 @@ LT_DEV void record_vertex(const WalkParams& P, unsigned long long rel, unsigned&
     }
 }
 
+// One deposit record per lane (or none) leaves the lane's run-length accumulator.  Atomic mode: a no-return
+// global atomic.  Log mode: the wave's records are compacted by ballot rank and appended, coalesced, to the wave's
+// current log chunk (SoA: voxel index, value); a chunk is claimed with one returning atomic per 4096 records.
+// If the log is exhausted the wave falls back to atomics, so a too-small log costs speed, never correctness.
+template <int TALLY>
+LT_DEV void emit_deposit(const WalkParams& P, bool has, unsigned idx, typename TallyT<TALLY>::type val,
+                         unsigned& lg_cur, unsigned& lg_end, unsigned& lg_chunk)
+{
+    typedef typename TallyT<TALLY>::type TV;
+    if (P.log_idx == nullptr) {
+        if (has) tally_add<TALLY>(P.grid, idx, val);
+        return;
+    }
+    const unsigned long long m = __ballot(has);
+    if (m == 0ull) return;
+    const unsigned cnt = (unsigned)__popcll(m);
+    if (lg_end - lg_cur < cnt) {
+        const int lane = threadIdx.x & 63;
+        if (lg_chunk != 0xffffffffu && lane == 0) P.log_fill[lg_chunk] = lg_cur - lg_chunk * kLogChunk;
+        unsigned c = 0;
+        if (lane == 0) c = __hip_atomic_fetch_add(P.log_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c < P.log_cap_chunks) { lg_chunk = c; lg_cur = c * kLogChunk; lg_end = lg_cur + kLogChunk; }
+        else { lg_chunk = 0xffffffffu; lg_cur = lg_end = 0; }
+    }
+    if (lg_chunk == 0xffffffffu) {  // log exhausted
+        if (has) tally_add<TALLY>(P.grid, idx, val);
+        return;
+    }
+    if (has) {
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        P.log_idx[lg_cur + rank] = idx;
+        reinterpret_cast<TV*>(P.log_val)[lg_cur + rank] = val;
+    }
+    lg_cur += cnt;
+}
+
 constexpr unsigned kPacket = 64;  // photon ids taken from the global queue per atomic
 
 // ---------------------------------------------------------------------------
 // the walk kernel
 // ---------------------------------------------------------------------------
+// minimum waves per SIMD the register allocator must leave room for (occupancy is what hides the latency of the
+// dependent f64 / transcendental chains once deposition no longer paces the walk)
+#ifndef LT_F64_WAVES
+#define LT_F64_WAVES 3
+#endif
+#ifndef LT_F32_WAVES
+#define LT_F32_WAVES 4
+#endif
 template <typename R, int GEOM, bool TABLE, int TALLY>
-__global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
+__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? LT_F64_WAVES : LT_F32_WAVES)) walk_kernel(const WalkParams P)
 {
     constexpr bool MESH = GEOM != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -435,6 +480,8 @@ __global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
     constexpr unsigned kNoVoxel = 0xffffffffu;
     unsigned pend_idx = kNoVoxel;
     TV pend_val = 0;
+    // wave-level deposit-log cursor (log mode): records [lg_cur, lg_end) of chunk lg_chunk are free
+    unsigned lg_cur = 0, lg_end = 0, lg_chunk = kNoVoxel;
     // wave-level packet of photon ids [pk_next, pk_end)
     unsigned long long pk_next = 0, pk_end = 0;
     bool q_done = false;
@@ -539,6 +586,8 @@ __global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
         if (!__any(alive)) break;  // wave-uniform: queue drained and every lane done
 
         // ---------------- one photon-step ----------------
+        unsigned f_idx = kNoVoxel;  // deposit record leaving the run-length accumulator this step
+        TV f_val = 0;
         if (alive) {
             if (step >= max_steps) {
                 atomicAdd(&s_cnt[CW_CAPPED], (double)w); alive = false;
@@ -628,10 +677,7 @@ __global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
                         const unsigned idx = ((unsigned)(int)fz * (unsigned)P.ny + (unsigned)(int)fy) * (unsigned)P.nx + (unsigned)(int)fx;
                         const TV q = tally_quantum<TALLY, R>(dw);
                         if (idx == pend_idx) pend_val += q;
-                        else {
-                            if (pend_idx != kNoVoxel) tally_add<TALLY>(P.grid, pend_idx, pend_val);
-                            pend_idx = idx; pend_val = q;
-                        }
+                        else { f_idx = pend_idx; f_val = pend_val; pend_idx = idx; pend_val = q; }
                         acc_abs += (double)dw;
                     } else {
                         acc_lost += (double)dw;
@@ -650,9 +696,11 @@ __global__ void __launch_bounds__(256) walk_kernel(const WalkParams P)
                 }
             }
         }
+        // wave-uniform point: send this step's records to the grid (atomics) or to the deposit log
+        emit_deposit<TALLY>(P, f_idx != kNoVoxel, f_idx, f_val, lg_cur, lg_end, lg_chunk);
     }
-
-    if (pend_idx != kNoVoxel) tally_add<TALLY>(P.grid, pend_idx, pend_val);
+    emit_deposit<TALLY>(P, pend_idx != kNoVoxel, pend_idx, pend_val, lg_cur, lg_end, lg_chunk);
+    if (P.log_idx && lg_chunk != kNoVoxel && (threadIdx.x & 63) == 0) P.log_fill[lg_chunk] = lg_cur - lg_chunk * kLogChunk;
 
     // ---------------- flush counters ----------------
     const double wa = wave_sum(acc_abs), wl = wave_sum(acc_lost);

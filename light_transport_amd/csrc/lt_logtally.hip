@@ -1,0 +1,249 @@
+// lt_logtally.hip -- reduction of the walk's deposit log into the voxel grid.
+//
+// Why: with per-deposit global atomics the walk runs at the memory-side atomic unit's request rate
+// (~16e9 requests/s) while its arithmetic alone would sustain 4x that.  MI355X has 288 GB of
+// HBM at ~6 TB/s of streaming bandwidth, so the deposits are instead WRITTEN as a coalesced log
+// (lt_kernels.hip: emit_deposit) and reduced here with streaming passes only:
+//   k_log_hist   records per grid tile (tile = 16384 consecutive voxels = one LDS-sized slab of the grid)
+//   k_log_scan   exclusive prefix -> where every tile's records will live; level-1 / level-2 cursors
+//   k_log_part   LSD-free two-level radix partition by tile id (pass 1: high digit, pass 2: low digit);
+//                a workgroup sorts 4096 records by digit in LDS and writes each digit's run contiguously
+//   k_log_reduce one workgroup per tile: LDS adds of all its records, then ONE plain read-add-write per
+//                touched voxel (the tile has exactly one owner, so no global atomics at all)
+// Integer (u64 fixed-point) tallies stay bit-identical to the atomic path; float tallies differ by summation
+// order only, as they already do between two atomic runs.
+#include <hip/hip_runtime.h>
+
+#include "lt_internal.hpp"
+
+namespace ltk {
+
+namespace {
+
+template <typename TV> __device__ __forceinline__ void lds_add(TV* p, TV v) { atomicAdd(p, v); }
+
+__device__ __forceinline__ unsigned tile_of(unsigned idx) { return idx >> kTileShift; }
+
+// records of one tile handled by one reduce workgroup; a tile with more records is split over several workgroups,
+// which bounds both the load imbalance and the same-address serialisation of the LDS adds on hot voxels
+constexpr uint32_t kReduceSlice = 131072;
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_log_hist(const uint32_t* __restrict__ log_idx, const uint32_t* __restrict__ fill,
+                                                  uint32_t n_chunks, uint32_t* __restrict__ hist, uint32_t n_tiles)
+{
+    extern __shared__ uint32_t s_h[];
+    for (uint32_t t = threadIdx.x; t < n_tiles; t += blockDim.x) s_h[t] = 0;
+    __syncthreads();
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const uint32_t n = fill[c];
+        const uint32_t* src = log_idx + (size_t)c * kLogChunk;
+        for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) atomicAdd(&s_h[tile_of(src[k])], 1u);
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < n_tiles; t += blockDim.x)
+        if (s_h[t]) atomicAdd(&hist[t], s_h[t]);
+}
+
+// one workgroup; n_tiles <= 131072 (2^31 voxels): a serial sweep by one lane is a few microseconds per 10^4 tiles
+__global__ void k_log_scan(const uint32_t* hist, uint32_t* tile_base, uint32_t* cursor1, uint32_t* cursor2,
+                           uint32_t* items2, uint32_t* items_r, uint32_t* totals, uint32_t n_tiles, uint32_t bits2)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t total = 0, ritems = 0;
+    for (uint32_t t = 0; t < n_tiles; t++) {
+        tile_base[t] = total; cursor2[t] = total; total += hist[t];
+        items_r[t] = ritems; ritems += (hist[t] + kReduceSlice - 1) / kReduceSlice;   // hot tiles get several workgroups
+    }
+    tile_base[n_tiles] = total; items_r[n_tiles] = ritems;
+    totals[2] = ritems;
+    const uint32_t nb1 = (n_tiles + (1u << bits2) - 1) >> bits2;
+    uint32_t items = 0;
+    for (uint32_t b = 0; b < nb1; b++) {
+        const uint32_t t0 = b << bits2, t1 = ((b + 1) << bits2) < n_tiles ? ((b + 1) << bits2) : n_tiles;
+        cursor1[b] = tile_base[t0];
+        items2[b] = items;
+        items += (tile_base[t1] - tile_base[t0] + kLogChunk - 1) / kLogChunk;
+    }
+    items2[nb1] = items;
+    totals[0] = total; totals[1] = items;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Partition work item: <= 4096 records.  Registers hold the item (16 records per lane), LDS holds the histogram
+// and the digit-sorted copy; each digit's run leaves as one contiguous, coalesced write.
+constexpr int kPartThreads = 256;
+constexpr int kPerThread = kLogChunk / kPartThreads;  // 16
+constexpr int kMaxBins = 512;
+
+template <typename TV, int PASS>
+__global__ void __launch_bounds__(kPartThreads) k_log_part(LogReduceParams L, uint32_t n_items)
+{
+    __shared__ uint32_t s_hist[kMaxBins], s_off[kMaxBins + 1], s_gbase[kMaxBins];
+    __shared__ uint32_t s_key[kLogChunk];
+    __shared__ TV s_val[kLogChunk];
+    __shared__ uint32_t s_range[3];
+
+    const uint32_t item = blockIdx.x;
+    if (item >= n_items) return;
+    const uint32_t nb1 = (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2;
+    const uint32_t mask2 = (1u << L.bits2) - 1;
+    const uint32_t* in_idx; const TV* in_val; uint32_t* out_idx; TV* out_val; uint32_t* cursor; uint32_t nb;
+    uint32_t lo, n;
+    if (PASS == 1) {
+        in_idx = L.log_idx; in_val = reinterpret_cast<const TV*>(L.log_val);
+        out_idx = L.tmp_idx; out_val = reinterpret_cast<TV*>(L.tmp_val);
+        lo = item * kLogChunk; n = L.log_fill[item];
+        cursor = L.cursor1; nb = nb1;
+    } else {
+        in_idx = L.tmp_idx; in_val = reinterpret_cast<const TV*>(L.tmp_val);
+        out_idx = const_cast<uint32_t*>(L.log_idx); out_val = reinterpret_cast<TV*>(const_cast<void*>(L.log_val));
+        if (threadIdx.x == 0) {  // which level-1 bin does this item belong to? (items2 is a prefix over bins)
+            uint32_t a = 0, b = nb1;
+            while (b - a > 1) { uint32_t m = (a + b) >> 1; if (L.items2[m] <= item) a = m; else b = m; }
+            const uint32_t t0 = a << L.bits2, t1 = ((a + 1) << L.bits2) < L.n_tiles ? ((a + 1) << L.bits2) : L.n_tiles;
+            const uint32_t rlo = L.tile_base[t0] + (item - L.items2[a]) * kLogChunk, rhi = L.tile_base[t1];
+            s_range[0] = rlo; s_range[1] = rhi - rlo < kLogChunk ? rhi - rlo : kLogChunk; s_range[2] = a;
+        }
+        __syncthreads();
+        lo = s_range[0]; n = s_range[1];
+        cursor = L.cursor2 + (s_range[2] << L.bits2); nb = 1u << L.bits2;
+    }
+    for (uint32_t d = threadIdx.x; d < nb; d += kPartThreads) s_hist[d] = 0;
+    __syncthreads();
+
+    uint32_t key[kPerThread], rank[kPerThread];
+    TV val[kPerThread];
+#pragma unroll
+    for (int r = 0; r < kPerThread; r++) {
+        const uint32_t k = threadIdx.x + r * kPartThreads;
+        if (k < n) { key[r] = in_idx[lo + k]; val[r] = in_val[lo + k]; }
+    }
+#pragma unroll
+    for (int r = 0; r < kPerThread; r++) {
+        const uint32_t k = threadIdx.x + r * kPartThreads;
+        if (k < n) {
+            const uint32_t t = tile_of(key[r]);
+            const uint32_t d = PASS == 1 ? (t >> L.bits2) : (t & mask2);
+            rank[r] = atomicAdd(&s_hist[d], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive prefix over <= 512 bins by one wave: 8 bins per lane + wave scan
+        const uint32_t per = (nb + 63) / 64;
+        uint32_t sum = 0;
+        for (uint32_t q = 0; q < per; q++) { const uint32_t d = threadIdx.x * per + q; if (d < nb) sum += s_hist[d]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { uint32_t o = __shfl_up(incl, off, 64); if ((int)threadIdx.x >= off) incl += o; }
+        uint32_t run = incl - sum;
+        for (uint32_t q = 0; q < per; q++) { const uint32_t d = threadIdx.x * per + q; if (d < nb) { s_off[d] = run; run += s_hist[d]; } }
+    }
+    for (uint32_t d = threadIdx.x; d < nb; d += kPartThreads)
+        if (s_hist[d]) s_gbase[d] = atomicAdd(&cursor[d], s_hist[d]);   // one returning atomic per non-empty digit
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kPerThread; r++) {
+        const uint32_t k = threadIdx.x + r * kPartThreads;
+        if (k < n) {
+            const uint32_t t = tile_of(key[r]);
+            const uint32_t d = PASS == 1 ? (t >> L.bits2) : (t & mask2);
+            const uint32_t p = s_off[d] + rank[r];
+            s_key[p] = key[r]; s_val[p] = val[r];
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < n; p += kPartThreads) {
+        const uint32_t kk = s_key[p];
+        const uint32_t t = tile_of(kk);
+        const uint32_t d = PASS == 1 ? (t >> L.bits2) : (t & mask2);
+        const uint32_t dst = s_gbase[d] + (p - s_off[d]);
+        out_idx[dst] = kk; out_val[dst] = s_val[p];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kReduceThreads = 512;
+
+template <typename TV>
+__global__ void __launch_bounds__(kReduceThreads) k_log_reduce(LogReduceParams L, uint32_t n_items)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    TV* s_tile = reinterpret_cast<TV*>(s_raw);
+    __shared__ uint32_t s_item[3];
+    const uint32_t item = blockIdx.x;
+    if (item >= n_items) return;
+    if (threadIdx.x == 0) {   // tile of this work item: items_r is a prefix over tiles
+        uint32_t a = 0, b = L.n_tiles;
+        while (b - a > 1) { uint32_t m = (a + b) >> 1; if (L.items_r[m] <= item) a = m; else b = m; }
+        const uint32_t lo = L.tile_base[a] + (item - L.items_r[a]) * kReduceSlice, end = L.tile_base[a + 1];
+        s_item[0] = a; s_item[1] = lo; s_item[2] = end - lo < kReduceSlice ? end : lo + kReduceSlice;
+    }
+    for (uint32_t v = threadIdx.x; v < kTileSize; v += kReduceThreads) s_tile[v] = 0;
+    __syncthreads();
+    const uint32_t t = s_item[0], lo = s_item[1], hi = s_item[2];
+    const bool shared_tile = L.items_r[t + 1] - L.items_r[t] > 1;
+    const uint32_t* idx = L.log_idx;
+    const TV* val = reinterpret_cast<const TV*>(L.log_val);
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += kReduceThreads) lds_add(&s_tile[idx[k] & (kTileSize - 1)], val[k]);
+    __syncthreads();
+    TV* grid = reinterpret_cast<TV*>(L.grid);
+    const size_t base = (size_t)t << kTileShift;
+    for (uint32_t v = threadIdx.x; v < kTileSize; v += kReduceThreads) {
+        const TV a = s_tile[v];
+        if (a != 0 && base + v < L.n_vox) {
+            if (shared_tile) __hip_atomic_fetch_add(&grid[base + v], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else grid[base + v] += a;   // exclusive owner of this tile: plain read-add-write
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_log_hist(const LogReduceParams& L, hipStream_t s)
+{
+    if (L.n_chunks == 0) return hipSuccess;
+    const unsigned blocks = L.n_chunks < 2048 ? L.n_chunks : 2048;
+    hipLaunchKernelGGL(k_log_hist, dim3(blocks), dim3(256), L.n_tiles * sizeof(uint32_t), s, L.log_idx, L.log_fill,
+                       L.n_chunks, L.hist, L.n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_log_scan(const LogReduceParams& L, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_log_scan, dim3(1), dim3(64), 0, s, L.hist, L.tile_base, L.cursor1, L.cursor2, L.items2, L.items_r, L.totals,
+                       L.n_tiles, L.bits2);
+    return hipGetLastError();
+}
+
+template <int PASS> static hipError_t launch_part(const LogReduceParams& L, uint32_t n_items, hipStream_t s)
+{
+    if (n_items == 0) return hipSuccess;
+    if (L.tally == LT_TALLY_F32) hipLaunchKernelGGL((k_log_part<float, PASS>), dim3(n_items), dim3(kPartThreads), 0, s, L, n_items);
+    else if (L.tally == LT_TALLY_F64) hipLaunchKernelGGL((k_log_part<double, PASS>), dim3(n_items), dim3(kPartThreads), 0, s, L, n_items);
+    else hipLaunchKernelGGL((k_log_part<unsigned long long, PASS>), dim3(n_items), dim3(kPartThreads), 0, s, L, n_items);
+    return hipGetLastError();
+}
+hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s) { return launch_part<1>(L, L.n_chunks, s); }
+hipError_t launch_log_part2(const LogReduceParams& L, uint32_t n_items, hipStream_t s) { return launch_part<2>(L, n_items, s); }
+
+template <typename TV> static hipError_t launch_reduce_t(const LogReduceParams& L, uint32_t n_items, hipStream_t s)
+{
+    const size_t lds = (size_t)kTileSize * sizeof(TV);
+    const void* fn = reinterpret_cast<const void*>(&k_log_reduce<TV>);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_log_reduce<TV>, dim3(n_items), dim3(kReduceThreads), lds, s, L, n_items);
+    return hipGetLastError();
+}
+hipError_t launch_log_reduce(const LogReduceParams& L, uint32_t n_items, hipStream_t s)
+{
+    if (n_items == 0) return hipSuccess;
+    if (L.tally == LT_TALLY_F32) return launch_reduce_t<float>(L, n_items, s);
+    if (L.tally == LT_TALLY_F64) return launch_reduce_t<double>(L, n_items, s);
+    return launch_reduce_t<unsigned long long>(L, n_items, s);
+}
+
+}  // namespace ltk

@@ -172,14 +172,17 @@ def test_c1_xorwow_parity_f64(ctx):
     assert abs(g.sum() - c["w_absorbed"]) < 1e-8
 
 
+@pytest.mark.parametrize("mode", ["log", "atomic"])
 @pytest.mark.parametrize("name", ["slab", "two_layer", "cornell", "thin_mismatched"])
-def test_fixed_point_tally_is_bit_exact(ctx, name):
+def test_fixed_point_tally_is_bit_exact(ctx, name, mode):
     prob = dict(slab=S.slab(), two_layer=S.two_layer(), cornell=S.cornell(48),
                 thin_mismatched=S.slab(media=((1.0, 9.0, 0.75, 1.4),), thickness=0.5, n=32, voxel=0.05,
                                        n_above=1.0, n_below=1.5))[name]
     n = 20000
     prob.apply(ctx, "u64fx")
+    ctx.set_tally_mode(mode)
     ctx.launch(n, seed=17); ctx.sync()
+    ctx.set_tally_mode("log")
     fx, c = ctx.read_grid_raw(), ctx.read_counters()
     _, fxo, co = prob.oracle().run(n, seed=17, threads=8, want_fx=True, want_f64=False)
     check_counters(c, co, n)
@@ -469,3 +472,30 @@ def test_light_subpath_vertices(ctx, name):
     np.testing.assert_allclose(paths[7][1].point, v["point"][7, 1], atol=1e-12)
     with pytest.raises(Exception):
         ctx.read_vertices(n)       # nothing captured by the last launch
+
+
+# ---------------------------------------------------------------- the two deposition paths
+def test_log_tally_equals_atomic_tally(ctx):
+    """LT_MODE_LOG (deposit log -> tile partition -> LDS reduce) against LT_MODE_ATOMIC: bit-identical fixed-point
+    grids, also when the log is far too small (many batches, overflow diverted to atomics) and on a grid whose
+    size is not a multiple of the 16384-voxel tile; float tallies equal up to summation order."""
+    odd = S.Problem([(0.1, 10.0, 0.9, 1.0)], (100, 70, 33), (-5.0, -3.5, 0.0), (0.1,) * 3,
+                    layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))
+    for prob, n in ((S.slab(), 300000), (odd, 300000), (S.cornell(64), 100000)):
+        grids = {}
+        for mode, log_bytes in (("atomic", 0), ("log", 8 << 30), ("log", 48 << 20)):
+            prob.apply(ctx, "u64fx"); ctx.set_tally_mode(mode, log_bytes)
+            ctx.launch(n, seed=5); ctx.sync()
+            grids[(mode, log_bytes)] = (ctx.read_grid_raw(), ctx.read_counters())
+        ref, cref = grids[("atomic", 0)]
+        for k, (g, c) in grids.items():
+            assert np.array_equal(g, ref), k
+            assert c["steps"] == cref["steps"] and c["photons"] == n
+        for dtype in ("f64", "f32"):
+            prob.apply(ctx, dtype); ctx.set_tally_mode("atomic"); ctx.launch(n, seed=5, f32_walk=dtype == "f32"); ctx.sync()
+            a = ctx.read_grid()
+            prob.apply(ctx, dtype); ctx.set_tally_mode("log", 8 << 30); ctx.launch(n, seed=5, f32_walk=dtype == "f32"); ctx.sync()
+            b = ctx.read_grid()
+            tol = 1e-11 if dtype == "f64" else 2e-3   # f32 sums of ~1e-2 deposits onto ~2e3: order matters at 1e-3
+            assert np.abs(a - b).max() <= tol * a.max()
+    ctx.set_tally_mode("log", 0)
