@@ -7,16 +7,18 @@
 
 One "step" = one complete job of config C2 on every rank: zero the tally, trace
 1e7 photons (homogeneous semi-infinite slab mu_a=0.1 mu_s=10 g=0.9 n=1, 256^3 grid
-of 0.1 mm voxels, pencil beam, f64 walk, XORWOW, f64 tally) and -- for N > 1 --
-sum-reduce the voxel grid + counters to rank 0 with RCCL.  Ranks trace disjoint
+of 0.1 mm voxels, pencil beam, f64 walk, XORWOW, f64 tally; deposits go through
+the log-structured tally: walk -> deposit log -> tile partition -> LDS reduce) and
+-- for N > 1 -- sum-reduce the voxel grid + counters to rank 0 with RCCL.  Ranks trace disjoint
 photon-id ranges (weak scaling: 1e7 photons per GPU); there is no other
 collective.  Inputs are synthetic by nature (the scene is ~100 bytes of constants,
 resident in HBM before the timed region).
 
 Prints ONE JSON line on rank 0:  metric = photon-steps/s over all ranks, plus
   roofline      algorithmic tally bytes (16 B per photon-step for the f64 tally:
-                8 B read + 8 B write of one voxel) / kernel time from HIP events
-                on the kernel's own stream, against the 8 TB/s HBM peak;
+                8 B read + 8 B write of one voxel) / device time of the job's
+                kernels (walk + log partition/reduce; HIP events on the ctx's own
+                stream), against the 8 TB/s HBM peak;
   cpu_baseline  the CPU oracle (oracle/, a port -- the reference has no such
                 path) on all host cores on a bounded sample of the same workload.
 """
@@ -76,6 +78,8 @@ def main():
     ap.add_argument("--f32-walk", action="store_true", help="f32 walk arithmetic (default f64, the reference's dtype)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--tally-mode", default="log", choices=["log", "atomic"],
+                    help="log: deposit log + tile partition + LDS reduce (default); atomic: one global atomic per deposit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -97,6 +101,7 @@ def main():
     from light_transport_amd import distributed as ltd
     ctx = lt.Context(local_rank)
     configure(ctx, args.tally)
+    ctx.set_tally_mode(args.tally_mode)
     if args.blocks_per_cu or args.threads:
         ctx.set_launch_config(args.blocks_per_cu, args.threads)
     info = ctx.device_info()
@@ -154,7 +159,8 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("%s_%s" % ("f32walk" if args.f32_walk else "f64walk", args.tally))
+                traffic = json.load(open(tf)).get("%s_%s_%s" % ("f32walk" if args.f32_walk else "f64walk", args.tally,
+                                                              args.tally_mode))
             except Exception:
                 traffic = None
         out = {
@@ -165,14 +171,14 @@ def main():
             "photons_per_sec": world * per_gpu * args.steps / elapsed,
             "config": {"workload": "C2: %.0e photons per GPU, homogeneous semi-infinite slab (mu_a=0.1, mu_s=10, g=0.9, "
                                    "n=1), %d^3 voxel grid (%.1f mm), pencil beam" % (per_gpu, GRID_N, VOXEL),
-                       "tally": args.tally, "rng": "rocRAND XORWOW, re-seeded per photon",
+                       "tally": args.tally, "tally_mode": args.tally_mode, "rng": "rocRAND XORWOW, re-seeded per photon",
                        "parallelism": "photon-id sharding x%d, RCCL reduce of the grid to rank 0 per step" % world
                        if world > 1 else "single GPU", "device": info["name"], "cus": info["cus"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "walk_kernel", "kernel_ms": kernel_avg_ms,
-                         "algorithmic_bytes_per_launch": steps_one_launch * BYTES_PER_STEP[args.tally],
-                         "atomics_per_sec": steps_one_launch / (kernel_avg_ms * 1e-3)},
+                         "kernel": "walk_kernel + k_log_hist/scan/part/reduce (one job)" if args.tally_mode == "log"
+                         else "walk_kernel", "kernel_ms": kernel_avg_ms,
+                         "algorithmic_bytes_per_launch": steps_one_launch * BYTES_PER_STEP[args.tally]},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

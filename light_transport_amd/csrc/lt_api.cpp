@@ -516,6 +516,8 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
 
     // ---- log-structured tally: walk -> deposit log -> partition by grid tile -> LDS tile reduce, in batches
     const uint32_t n_tiles = (uint32_t)((c->n_vox() + kTileSize - 1) >> kTileShift);
+    const uint32_t n_tiles_pre = (uint32_t)((c->n_vox() + kTileSize - 1) >> kTileShift);
+    (void)n_tiles_pre;
     const bool use_log = c->tally_mode == 1 && !v.table && c->max_vertices == 0 && n_tiles <= 16384 && !std::getenv("LT_DIAG_NO_TALLY");
     if (use_log) {
         const size_t rec_bytes = 4 + c->grid_elem();
@@ -553,6 +555,10 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         HIP_TRY(c, ensure_log());
         HIP_TRY(c, c->d_log_meta.ensure(64));
         uint32_t bits2 = 1; while ((1u << (2 * bits2)) < n_tiles) bits2++;
+        // grids of <= 1024 tiles (256^3): ONE partition pass straight to tiles.  Records cluster in the few dozen
+        // tiles around the source, so the per-tile runs of a 4096-record work item stay long enough to coalesce.
+        if (n_tiles <= 1024) bits2 = 0;
+        if (const char* e = std::getenv("LT_LOG_BITS2")) bits2 = (uint32_t)std::atoi(e);
         const uint32_t nb1 = (n_tiles + (1u << bits2) - 1) >> bits2;
         HIP_TRY(c, c->d_hist.ensure((size_t)n_tiles * 4)); HIP_TRY(c, c->d_tile_base.ensure((size_t)(n_tiles + 1) * 4));
         HIP_TRY(c, c->d_cursor1.ensure((size_t)nb1 * 4)); HIP_TRY(c, c->d_cursor2.ensure((size_t)n_tiles * 4));
@@ -560,6 +566,14 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         uint32_t* meta = (uint32_t*)c->d_log_meta.p;   // [0] next chunk, [2..3] totals
         P.log_idx = (uint32_t*)c->d_log_idx.p; P.log_val = c->d_log_val.p; P.log_fill = (uint32_t*)c->d_log_fill.p;
         P.log_next = meta; P.log_cap_chunks = cap_chunks;
+        P.log_hist = (uint32_t*)c->d_hist.p; P.log_n_tiles = n_tiles;
+        cfg.lds_bytes = walk_lds_bytes(v, P.n_media, P.n_layers, P.n_tris, P.n_nodes, n_tiles);
+        {
+            const int res2 = walk_max_blocks_per_cu(v, cfg.threads, cfg.lds_bytes);
+            if (res2 <= 0) return c->fail(LT_E_HIP, "lt_launch: log-mode kernel not resident");
+            const int pc = c->blocks_per_cu > 0 ? c->blocks_per_cu : res2;
+            cap = (unsigned long long)pc * (unsigned long long)c->prop.multiProcessorCount;
+        }
         LogReduceParams L;
         std::memset(&L, 0, sizeof L);
         L.log_idx = P.log_idx; L.log_val = P.log_val; L.log_fill = P.log_fill;
@@ -610,8 +624,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
             const bool overflow = h[0] > cap_chunks;
             L.n_chunks = h[0] < cap_chunks ? h[0] : cap_chunks;
             if (diag) HIP_TRY(c, hipEventRecord(te[1], c->stream));
-            HIP_TRY(c, launch_log_hist(L, c->stream));
-            if (diag) HIP_TRY(c, hipEventRecord(te[2], c->stream));
+            if (diag) HIP_TRY(c, hipEventRecord(te[2], c->stream));   // (tile histogram now comes from the walk)
             HIP_TRY(c, launch_log_scan(L, c->stream));
             if (diag) HIP_TRY(c, hipEventRecord(te[3], c->stream));
             HIP_TRY(c, hipMemcpyAsync(h + 2, meta + 2, 12, hipMemcpyDeviceToHost, c->stream));
@@ -619,9 +632,11 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
             if (diag) HIP_TRY(c, hipEventRecord(te[3], c->stream));
             HIP_TRY(c, launch_log_part1(L, c->stream));
             if (diag) HIP_TRY(c, hipEventRecord(te[4], c->stream));
-            HIP_TRY(c, launch_log_part2(L, h[3], c->stream));
+            LogReduceParams Lr = L;
+            if (bits2 == 0) { Lr.log_idx = L.tmp_idx; Lr.log_val = L.tmp_val; }   // single pass: tiles are final in tmp
+            else HIP_TRY(c, launch_log_part2(L, h[3], c->stream));
             if (diag) HIP_TRY(c, hipEventRecord(te[5], c->stream));
-            HIP_TRY(c, launch_log_reduce(L, h[4], c->stream));
+            HIP_TRY(c, launch_log_reduce(Lr, h[4], c->stream));
             if (diag) {
                 HIP_TRY(c, hipEventRecord(te[6], c->stream));
                 HIP_TRY(c, hipEventSynchronize(te[6]));

@@ -74,6 +74,8 @@ struct WalkParams {
     uint32_t* log_fill;   // [log_cap_chunks] valid records per chunk
     uint32_t* log_next;   // next free chunk
     uint32_t log_cap_chunks;
+    uint32_t* log_hist;   // [log_n_tiles] records per grid tile, accumulated by the walk (LDS histogram per workgroup)
+    uint32_t log_n_tiles;
     // light sub-path capture (null = off)
     lt_vertex* vertices;
     uint32_t* vertex_counts;
@@ -94,7 +96,7 @@ struct Variant {
 };
 
 hipError_t launch_walk(const WalkParams& P, const Variant& v, const LaunchCfg& cfg, hipStream_t s);
-size_t walk_lds_bytes(const Variant& v, int n_media, int n_layers, int n_tris, int n_nodes);
+size_t walk_lds_bytes(const Variant& v, int n_media, int n_layers, int n_tris, int n_nodes, unsigned n_hist = 0);
 // resident-blocks-per-CU the runtime reports for a variant at `threads`
 int walk_max_blocks_per_cu(const Variant& v, int threads, size_t lds_bytes);
 

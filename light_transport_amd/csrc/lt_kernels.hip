@@ -330,8 +330,8 @@ template <int TALLY> LT_DEV void tally_add(void* grid, unsigned idx, typename Ta
 LT_DEV size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 template <typename R> struct LdsLayout {
-    size_t off_cnt, off_media, off_zb, off_lm, off_tris, off_nodes, total;
-    __host__ __device__ LdsLayout(int n_media, int n_layers, int n_tris, int n_nodes)
+    size_t off_cnt, off_media, off_zb, off_lm, off_tris, off_nodes, off_hist, total;
+    __host__ __device__ LdsLayout(int n_media, int n_layers, int n_tris, int n_nodes, unsigned n_hist = 0)
     {
         auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
         size_t o = 0;
@@ -341,6 +341,7 @@ template <typename R> struct LdsLayout {
         off_lm = o;    o = al(o + (size_t)(n_layers > 0 ? n_layers : 1) * sizeof(int32_t));
         off_tris = o;  o = al(o + (size_t)n_tris * sizeof(TriD<R>));
         off_nodes = o; o = al(o + (size_t)n_nodes * sizeof(NodeD<R>));
+        off_hist = o;  o = al(o + (size_t)n_hist * sizeof(uint32_t));
         total = o;
     }
 };
@@ -388,7 +389,7 @@ LT_DEV void record_vertex(const WalkParams& P, unsigned long long rel, unsigned&
 // If the log is exhausted the wave falls back to atomics, so a too-small log costs speed, never correctness.
 template <int TALLY>
 LT_DEV void emit_deposit(const WalkParams& P, bool has, unsigned idx, typename TallyT<TALLY>::type val,
-                         unsigned& lg_cur, unsigned& lg_end, unsigned& lg_chunk)
+                         unsigned& lg_cur, unsigned& lg_end, unsigned& lg_chunk, uint32_t* s_hist)
 {
     typedef typename TallyT<TALLY>::type TV;
     if (P.log_idx == nullptr) {
@@ -415,6 +416,7 @@ LT_DEV void emit_deposit(const WalkParams& P, bool has, unsigned idx, typename T
         const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         P.log_idx[lg_cur + rank] = idx;
         reinterpret_cast<TV*>(P.log_val)[lg_cur + rank] = val;
+        atomicAdd(&s_hist[idx >> kTileShift], 1u);   // tile histogram for the partition pass, kept in LDS
     }
     lg_cur += cnt;
 }
@@ -439,7 +441,10 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? LT_F64_WAVES : LT_F32_W
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // GEOM 2: the mesh is too large for LDS -> triangles and nodes are read from global memory (they are
     // read-only and shared by every wave, so they live in the XCD L2s / Infinity Cache after first touch)
-    const LdsLayout<R> L(P.n_media, P.n_layers, GEOM == 1 ? P.n_tris : 0, GEOM == 1 ? P.n_nodes : 0);
+    const LdsLayout<R> L(P.n_media, P.n_layers, GEOM == 1 ? P.n_tris : 0, GEOM == 1 ? P.n_nodes : 0,
+                         P.log_idx ? P.log_n_tiles : 0u);
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds_raw + L.off_hist);   // log mode: records per grid tile
+    if (P.log_idx) for (unsigned t = threadIdx.x; t < P.log_n_tiles; t += blockDim.x) s_hist[t] = 0;
     double* s_cnt = reinterpret_cast<double*>(lds_raw + L.off_cnt);
     const MedD<R>* s_med = reinterpret_cast<const MedD<R>*>(lds_raw + L.off_media);
     const R* s_zb = reinterpret_cast<const R*>(lds_raw + L.off_zb);
@@ -697,9 +702,9 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? LT_F64_WAVES : LT_F32_W
             }
         }
         // wave-uniform point: send this step's records to the grid (atomics) or to the deposit log
-        emit_deposit<TALLY>(P, f_idx != kNoVoxel, f_idx, f_val, lg_cur, lg_end, lg_chunk);
+        emit_deposit<TALLY>(P, f_idx != kNoVoxel, f_idx, f_val, lg_cur, lg_end, lg_chunk, s_hist);
     }
-    emit_deposit<TALLY>(P, pend_idx != kNoVoxel, pend_idx, pend_val, lg_cur, lg_end, lg_chunk);
+    emit_deposit<TALLY>(P, pend_idx != kNoVoxel, pend_idx, pend_val, lg_cur, lg_end, lg_chunk, s_hist);
     if (P.log_idx && lg_chunk != kNoVoxel && (threadIdx.x & 63) == 0) P.log_fill[lg_chunk] = lg_cur - lg_chunk * kLogChunk;
 
     // ---------------- flush counters ----------------
@@ -711,6 +716,9 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? LT_F64_WAVES : LT_F32_W
         __hip_atomic_fetch_add(&P.counters->steps, ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    if (P.log_idx)
+        for (unsigned t = threadIdx.x; t < P.log_n_tiles; t += blockDim.x)
+            if (s_hist[t]) __hip_atomic_fetch_add(&P.log_hist[t], s_hist[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (blockIdx.x == 0 && threadIdx.x == 8)
         __hip_atomic_fetch_add(&P.counters->photons, P.n_photons, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x < 8)
@@ -749,12 +757,12 @@ static WalkFn pick(const Variant& v)
     return v.table ? pick_geom<double, true>(v) : pick_geom<double, false>(v);
 }
 
-size_t walk_lds_bytes(const Variant& v, int n_media, int n_layers, int n_tris, int n_nodes)
+size_t walk_lds_bytes(const Variant& v, int n_media, int n_layers, int n_tris, int n_nodes, unsigned n_hist)
 {
     if (v.mesh) n_layers = 0;
     if (v.mesh != 1) { n_tris = 0; n_nodes = 0; }
-    return v.f32 ? LdsLayout<float>(n_media, n_layers, n_tris, n_nodes).total
-                 : LdsLayout<double>(n_media, n_layers, n_tris, n_nodes).total;
+    return v.f32 ? LdsLayout<float>(n_media, n_layers, n_tris, n_nodes, n_hist).total
+                 : LdsLayout<double>(n_media, n_layers, n_tris, n_nodes, n_hist).total;
 }
 
 int walk_max_blocks_per_cu(const Variant& v, int threads, size_t lds_bytes)

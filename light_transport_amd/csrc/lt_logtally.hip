@@ -74,7 +74,7 @@ __global__ void k_log_scan(const uint32_t* hist, uint32_t* tile_base, uint32_t* 
 // and the digit-sorted copy; each digit's run leaves as one contiguous, coalesced write.
 constexpr int kPartThreads = 256;
 constexpr int kPerThread = kLogChunk / kPartThreads;  // 16
-constexpr int kMaxBins = 512;
+constexpr int kMaxBins = 1024;
 
 template <typename TV, int PASS>
 __global__ void __launch_bounds__(kPartThreads) k_log_part(LogReduceParams L, uint32_t n_items)

@@ -481,7 +481,9 @@ def test_log_tally_equals_atomic_tally(ctx):
     size is not a multiple of the 16384-voxel tile; float tallies equal up to summation order."""
     odd = S.Problem([(0.1, 10.0, 0.9, 1.0)], (100, 70, 33), (-5.0, -3.5, 0.0), (0.1,) * 3,
                     layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))
-    for prob, n in ((S.slab(), 300000), (odd, 300000), (S.cornell(64), 100000)):
+    big = S.Problem([(0.1, 10.0, 0.9, 1.0)], (300, 300, 200), (-15.0, -15.0, 0.0), (0.1,) * 3,
+                    layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))   # 1099 tiles: two-level partition
+    for prob, n in ((S.slab(), 300000), (odd, 300000), (S.cornell(64), 100000), (big, 300000)):
         grids = {}
         for mode, log_bytes in (("atomic", 0), ("log", 8 << 30), ("log", 48 << 20)):
             prob.apply(ctx, "u64fx"); ctx.set_tally_mode(mode, log_bytes)
