@@ -22,6 +22,11 @@ namespace {
 
 template <typename TV> __device__ __forceinline__ void lds_add(TV* p, TV v) { atomicAdd(p, v); }
 
+// type the LDS tile accumulates in: f32 deposits are summed in f64 (ds_add_f64 sustains twice the rate of
+// ds_add_f32 on the hot voxels here, and the f32 grid then sees one rounding per tile instead of one per deposit)
+template <typename TV> struct AccT { typedef TV type; };
+template <> struct AccT<float> { typedef double type; };
+
 __device__ __forceinline__ unsigned tile_of(unsigned idx) { return idx >> kTileShift; }
 
 // records of one tile handled by one reduce workgroup; a tile with more records is split over several workgroups,
@@ -168,8 +173,9 @@ constexpr int kReduceThreads = 512;
 template <typename TV>
 __global__ void __launch_bounds__(kReduceThreads) k_log_reduce(LogReduceParams L, uint32_t n_items)
 {
+    typedef typename AccT<TV>::type AT;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    TV* s_tile = reinterpret_cast<TV*>(s_raw);
+    AT* s_tile = reinterpret_cast<AT*>(s_raw);
     __shared__ uint32_t s_item[3];
     const uint32_t item = blockIdx.x;
     if (item >= n_items) return;
@@ -185,12 +191,21 @@ __global__ void __launch_bounds__(kReduceThreads) k_log_reduce(LogReduceParams L
     const bool shared_tile = L.items_r[t + 1] - L.items_r[t] > 1;
     const uint32_t* idx = L.log_idx;
     const TV* val = reinterpret_cast<const TV*>(L.log_val);
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += kReduceThreads) lds_add(&s_tile[idx[k] & (kTileSize - 1)], val[k]);
+    // four independent records in flight per lane (the tile pins the workgroup at 8 waves per CU, so memory-level
+    // parallelism has to come from the instruction stream)
+    uint32_t k = lo + threadIdx.x;
+    for (; k + 3 * kReduceThreads < hi; k += 4 * kReduceThreads) {
+        const uint32_t i0 = idx[k], i1 = idx[k + kReduceThreads], i2 = idx[k + 2 * kReduceThreads], i3 = idx[k + 3 * kReduceThreads];
+        const TV v0 = val[k], v1 = val[k + kReduceThreads], v2 = val[k + 2 * kReduceThreads], v3 = val[k + 3 * kReduceThreads];
+        lds_add(&s_tile[i0 & (kTileSize - 1)], (AT)v0); lds_add(&s_tile[i1 & (kTileSize - 1)], (AT)v1);
+        lds_add(&s_tile[i2 & (kTileSize - 1)], (AT)v2); lds_add(&s_tile[i3 & (kTileSize - 1)], (AT)v3);
+    }
+    for (; k < hi; k += kReduceThreads) lds_add(&s_tile[idx[k] & (kTileSize - 1)], (AT)val[k]);
     __syncthreads();
     TV* grid = reinterpret_cast<TV*>(L.grid);
     const size_t base = (size_t)t << kTileShift;
     for (uint32_t v = threadIdx.x; v < kTileSize; v += kReduceThreads) {
-        const TV a = s_tile[v];
+        const TV a = (TV)s_tile[v];
         if (a != 0 && base + v < L.n_vox) {
             if (shared_tile) __hip_atomic_fetch_add(&grid[base + v], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else grid[base + v] += a;   // exclusive owner of this tile: plain read-add-write
@@ -229,7 +244,7 @@ hipError_t launch_log_part2(const LogReduceParams& L, uint32_t n_items, hipStrea
 
 template <typename TV> static hipError_t launch_reduce_t(const LogReduceParams& L, uint32_t n_items, hipStream_t s)
 {
-    const size_t lds = (size_t)kTileSize * sizeof(TV);
+    const size_t lds = (size_t)kTileSize * sizeof(typename AccT<TV>::type);
     const void* fn = reinterpret_cast<const void*>(&k_log_reduce<TV>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
