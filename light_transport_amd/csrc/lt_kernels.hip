@@ -32,6 +32,83 @@ namespace ltk {
 // ---------------------------------------------------------------------------
 // precision traits
 // ---------------------------------------------------------------------------
+// Lean f64 primitives for the walk's restricted argument ranges.  OCML's general-purpose f64 log / sincospi /
+// sqrt / division cost 98 / 71 / 22 / 12 VALU instructions each because they cover denormals, huge arguments and
+// correct rounding; the walk only ever needs -ln(xi) for xi in [2^-53, 1], sin/cos of a turn fraction in (0, 1],
+// sqrt on [0, 1] and quotients of well-scaled numbers.  These versions are accurate to ~1-2 ulp (checked against
+// the host libm in tests/test_gpu_parity.py through lt_eval) at 35 / 38 / 9 / 8 instructions.
+LT_DEV double fast_rcp(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);                 // v_rcp_f64: ~26 good bits
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return r;
+}
+LT_DEV double fast_div(double a, double b)
+{
+    const double r = fast_rcp(b);
+    const double q = a * r;
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q); // one residual correction
+}
+LT_DEV double sqrt01(double x)                           // x in [0, 1] (0 exactly allowed)
+{
+    double y = __builtin_amdgcn_rsq(x > 0.0 ? x : 1.0);  // v_rsq_f64
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return x > 0.0 ? g : 0.0;
+}
+LT_DEV double neg_log_unit(double x)                     // -ln(x), x in [2^-53, 1]
+{
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);           // [0.5, 1)
+    if (m < 0.70710678118654752) { m += m; e -= 1; }     // -> [sqrt(1/2), sqrt(2))
+    const double f = m - 1.0;
+    const double s = fast_div(f, 2.0 + f);               // (m - 1) / (m + 1), |s| <= 0.1716
+    const double z = s * s;
+    // ln(m) = 2 s (1 + z/3 + z^2/5 + ... + z^10/21); the truncated tail is < 3e-18 relative
+    double p = 1.0 / 21.0;
+    p = __builtin_fma(p, z, 1.0 / 19.0); p = __builtin_fma(p, z, 1.0 / 17.0); p = __builtin_fma(p, z, 1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0); p = __builtin_fma(p, z, 1.0 / 11.0); p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, 1.0 / 7.0);  p = __builtin_fma(p, z, 1.0 / 5.0);  p = __builtin_fma(p, z, 1.0 / 3.0);
+    const double lnm = __builtin_fma(2.0 * s * z, p, 2.0 * s);
+    const double de = (double)e;
+    // ln 2 split so that e * hi is exact for |e| <= 53
+    return -__builtin_fma(de, 6.93147180369123816490e-01, __builtin_fma(de, 1.90821492927058770002e-10, lnm));
+}
+LT_DEV void sincos_turn_f64(double xi, double* sn, double* cs)  // sin, cos of 2*pi*xi, xi in (0, 1]
+{
+    const double t = 4.0 * xi;                           // exact
+    const double qf = __builtin_rint(t);
+    const double a = (t - qf) * 1.57079632679489661923;  // (t - qf) exact, |a| <= pi/4
+    const double z = a * a;
+    double ps = -7.6471637318198164759e-13;              // -1/15!
+    ps = __builtin_fma(ps, z, 1.6059043836821614599e-10);   //  1/13!
+    ps = __builtin_fma(ps, z, -2.5052108385441718775e-08);  // -1/11!
+    ps = __builtin_fma(ps, z, 2.7557319223985890653e-06);   //  1/9!
+    ps = __builtin_fma(ps, z, -1.9841269841269841270e-04);  // -1/7!
+    ps = __builtin_fma(ps, z, 8.3333333333333333333e-03);   //  1/5!
+    ps = __builtin_fma(ps, z, -1.6666666666666666667e-01);  // -1/3!
+    const double s = __builtin_fma(a * z, ps, a);
+    double pc = 4.7794773323873852974e-14;               //  1/16!
+    pc = __builtin_fma(pc, z, -1.1470745597729724714e-11);  // -1/14!
+    pc = __builtin_fma(pc, z, 2.0876756987868098979e-09);   //  1/12!
+    pc = __builtin_fma(pc, z, -2.7557319223985890653e-07);  // -1/10!
+    pc = __builtin_fma(pc, z, 2.4801587301587301587e-05);   //  1/8!
+    pc = __builtin_fma(pc, z, -1.3888888888888888889e-03);  // -1/6!
+    pc = __builtin_fma(pc, z, 4.1666666666666666667e-02);   //  1/4!
+    pc = __builtin_fma(pc, z, -0.5);
+    const double c = __builtin_fma(pc, z, 1.0);
+    const int q = (int)qf & 3;                           // quadrant rotation
+    const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
 template <typename R> struct Mx;
 template <> struct Mx<double> {
     static LT_DEV double log(double x) { return ::log(x); }
@@ -39,8 +116,11 @@ template <> struct Mx<double> {
     static LT_DEV double abs(double x) { return ::fabs(x); }
     static LT_DEV double sin(double x) { return ::sin(x); }
     static LT_DEV double cos(double x) { return ::cos(x); }
-    // sin/cos of 2*pi*xi without a range reduction by pi
-    static LT_DEV void sincos_turn(double xi, double* s, double* c) { ::sincospi(2.0 * xi, s, c); }
+    // the hot-loop forms (restricted ranges, see above)
+    static LT_DEV double neg_log(double xi) { return neg_log_unit(xi); }
+    static LT_DEV double sqrt_unit(double x) { return sqrt01(x); }
+    static LT_DEV double quot(double a, double b) { return fast_div(a, b); }
+    static LT_DEV void sincos_turn(double xi, double* s, double* c) { sincos_turn_f64(xi, s, c); }
     static LT_DEV double inf() { return __builtin_huge_val(); }
     static LT_DEV double uniform(rocrand_state_xorwow* st) { return rocrand_uniform_double(st); }
 };
@@ -50,6 +130,9 @@ template <> struct Mx<float> {
     static LT_DEV float abs(float x) { return ::fabsf(x); }
     static LT_DEV float sin(float x) { return ::sinf(x); }
     static LT_DEV float cos(float x) { return ::cosf(x); }
+    static LT_DEV float neg_log(float xi) { return -::logf(xi); }
+    static LT_DEV float sqrt_unit(float x) { return ::sqrtf(x); }
+    static LT_DEV float quot(float a, float b) { return a / b; }
     static LT_DEV void sincos_turn(float xi, float* s, float* c) { ::sincospif(2.0f * xi, s, c); }
     static LT_DEV float inf() { return __builtin_huge_valf(); }
     static LT_DEV float uniform(rocrand_state_xorwow* st) { return rocrand_uniform(st); }
@@ -191,7 +274,7 @@ template <typename R> LT_DEV R hg_sample(R xi, R g, R one_m_g2, R one_p_g2, R in
     R c;
     if (g == 0) c = (R)2 * xi - (R)1;
     else {
-        R t = one_m_g2 / ((R)1 - g + (R)2 * g * xi);
+        R t = Mx<R>::quot(one_m_g2, (R)1 - g + (R)2 * g * xi);
         c = (one_p_g2 - t * t) * inv_2g;
     }
     c = c > 1 ? (R)1 : c;
@@ -276,16 +359,16 @@ template <typename R> LT_DEV R boundary(const R* d, const R* nf, R n1, R n2, R* 
 template <typename R> LT_DEV void spin(R* u, R ct, R xi_phi)
 {
     R st2 = (R)1 - ct * ct;
-    R st = Mx<R>::sqrt(st2 > 0 ? st2 : (R)0);
+    R st = Mx<R>::sqrt_unit(st2 > 0 ? st2 : (R)0);
     R sp, cp; Mx<R>::sincos_turn(xi_phi, &sp, &cp);
     R ux = u[0], uy = u[1], uz = u[2];
     if (Mx<R>::abs(uz) > (R)0.99999) {
         u[0] = st * cp; u[1] = st * sp; u[2] = uz >= 0 ? ct : -ct;
     } else {
         R t2 = (R)1 - uz * uz;
-        R tmp = Mx<R>::sqrt(t2);
-        u[0] = st * (ux * uz * cp - uy * sp) / tmp + ux * ct;
-        u[1] = st * (uy * uz * cp + ux * sp) / tmp + uy * ct;
+        R tmp = Mx<R>::sqrt_unit(t2);
+        u[0] = Mx<R>::quot(st * (ux * uz * cp - uy * sp), tmp) + ux * ct;
+        u[1] = Mx<R>::quot(st * (uy * uz * cp + ux * sp), tmp) + uy * ct;
         u[2] = -st * cp * tmp + uz * ct;
     }
 }
@@ -611,7 +694,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? LT_F64_WAVES : LT_F32_W
                 grp++;
                 const MedD<R>* Mp = &s_med[MESH ? cur : s_lm[cur]];
                 const R mu_t = Mp->mu_t;
-                if (sleft == 0) sleft = -Mx<R>::log(u4[0]);
+                if (sleft == 0) sleft = Mx<R>::neg_log(u4[0]);
                 const R s = (mu_t > 0) ? sleft * Mp->inv_mu_t : inf;
 
                 // ---- hop: distance to the next boundary ----
@@ -877,6 +960,13 @@ __global__ void k_eval(int fn, const double* in, size_t n, double* out)
         double u[3] = {in[5 * i], in[5 * i + 1], in[5 * i + 2]};
         spin(u, in[5 * i + 3], in[5 * i + 4]);
         for (int k = 0; k < 3; k++) out[3 * i + k] = u[k];
+    } break;
+    case LT_FN_WALK_MATH: {   // the walk's lean f64 primitives: -ln x, sin/cos(2 pi x), sqrt x, 1 / (1 + x)
+        const double x = in[i];
+        out[5 * i] = neg_log_unit(x);
+        sincos_turn_f64(x, &out[5 * i + 1], &out[5 * i + 2]);
+        out[5 * i + 3] = sqrt01(x);
+        out[5 * i + 4] = fast_div(1.0, 1.0 + x);
     } break;
     }
 }

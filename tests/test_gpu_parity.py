@@ -133,6 +133,29 @@ def test_boundary_and_spin_match_oracle(ctx):
     np.testing.assert_allclose(np.linalg.norm(a, axis=1), 1.0, atol=1e-5)   # 0.99999 branch is approximate by design
 
 
+def test_walk_math_primitives(ctx):
+    """The walk's lean f64 -ln, sin/cos(2 pi x), sqrt and quotient (restricted ranges) against the host libm."""
+    rs = np.random.RandomState(2)
+    x = np.concatenate([rs.rand(200000), 2.0 ** -np.arange(1, 54), 1 - 2.0 ** -np.arange(1, 54), [1.0, 0.5, 0.25, 0.75,
+                        0.125, 0.70710678118654752, 0.7071067811865476, 2.0 ** -53]])
+    x = x[x > 0]
+    out = ctx.eval("WALK_MATH", x[:, None])
+    ref = -np.log(x)
+    assert np.all(np.abs(out[:, 0] - ref) <= 4e-16 * np.maximum(np.abs(ref), 2.0 ** -53)), "neg_log"
+    assert out[x == 1.0, 0].max() == 0.0
+    # reference in x87 extended precision: in double, 2*pi*x alone carries up to 7e-16 of angle error
+    two_pi = 2 * np.longdouble("3.14159265358979323846264338327950288")
+    ang = two_pi * x.astype(np.longdouble)
+    np.testing.assert_allclose(out[:, 1], np.sin(ang).astype(np.float64), rtol=0, atol=3e-16)
+    np.testing.assert_allclose(out[:, 2], np.cos(ang).astype(np.float64), rtol=0, atol=3e-16)
+    np.testing.assert_allclose(out[:, 1] ** 2 + out[:, 2] ** 2, 1.0, rtol=0, atol=5e-16)
+    np.testing.assert_allclose(out[:, 3], np.sqrt(x), rtol=3e-16, atol=0)
+    np.testing.assert_allclose(out[:, 4], 1.0 / (1.0 + x), rtol=3e-16, atol=0)
+    z = ctx.eval("WALK_MATH", np.array([[1.0]]))   # exact corners used by the walk
+    assert z[0, 1] == 0.0 or abs(z[0, 1]) < 1e-300 or abs(z[0, 1]) < 3e-16
+    assert abs(z[0, 2] - 1.0) < 3e-16 and z[0, 3] == 1.0
+
+
 # ---------------------------------------------------------------- the walk vs the oracle
 def run_gpu(ctx, prob, n, dtype="f64", **kw):
     prob.apply(ctx, dtype)
