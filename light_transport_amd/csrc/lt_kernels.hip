@@ -123,6 +123,9 @@ template <> struct Mx<double> {
     static LT_DEV void sincos_turn(double xi, double* s, double* c) { sincos_turn_f64(xi, s, c); }
     static LT_DEV double inf() { return __builtin_huge_val(); }
     static LT_DEV double uniform(rocrand_state_xorwow* st) { return rocrand_uniform_double(st); }
+    // 32-bit-resolution uniform in (0,1] from ONE draw (rocrand_uniform.h:97-100); used for the three
+    // decision/angle uniforms of a step, where 2^-32 is far below any physical resolution
+    static LT_DEV double uniform32(rocrand_state_xorwow* st) { return rocrand_device::detail::uniform_distribution_double(rocrand(st)); }
 };
 template <> struct Mx<float> {
     static LT_DEV float log(float x) { return ::logf(x); }
@@ -136,6 +139,7 @@ template <> struct Mx<float> {
     static LT_DEV void sincos_turn(float xi, float* s, float* c) { ::sincospif(2.0f * xi, s, c); }
     static LT_DEV float inf() { return __builtin_huge_valf(); }
     static LT_DEV float uniform(rocrand_state_xorwow* st) { return rocrand_uniform(st); }
+    static LT_DEV float uniform32(rocrand_state_xorwow* st) { return rocrand_uniform(st); }
 };
 
 template <typename R> LT_DEV R dot3(const R* a, const R* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -624,8 +628,9 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? LT_F64_WAVES : LT_F32_W
 #pragma unroll
                         for (int k = 0; k < 4; k++) u4[k] = (R)(1.0 - t[k]);
                     } else {
+                        u4[0] = Mx<R>::uniform(&rng);
 #pragma unroll
-                        for (int k = 0; k < 4; k++) u4[k] = Mx<R>::uniform(&rng);
+                        for (int k = 1; k < 4; k++) u4[k] = Mx<R>::uniform32(&rng);
                     }
                     grp++;
                     R nrm[3] = {(R)P.src_dir[0], (R)P.src_dir[1], (R)P.src_dir[2]};
@@ -687,9 +692,10 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? LT_F64_WAVES : LT_F32_W
                     const double* t = P.table + ((pid - P.photon_offset) * P.table_steps + grp) * 4;
 #pragma unroll
                     for (int k = 0; k < 4; k++) u4[k] = (R)(1.0 - t[k]);
-                } else {
+                } else {   // xi0 (step length) with 53 bits, xi1..xi3 with 32 bits: 5 XORWOW draws per step
+                    u4[0] = Mx<R>::uniform(&rng);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) u4[k] = Mx<R>::uniform(&rng);
+                    for (int k = 1; k < 4; k++) u4[k] = Mx<R>::uniform32(&rng);
                 }
                 grp++;
                 const MedD<R>* Mp = &s_med[MESH ? cur : s_lm[cur]];

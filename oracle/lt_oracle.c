@@ -58,11 +58,17 @@ static inline double lto_uniform_f64(lto_xorwow* s)
     uint64_t v = ((uint64_t)(v2 >> 11) << 32) | (uint64_t)v1;
     return 1.1102230246251565e-16 + (double)v * 1.1102230246251565e-16;
 }
+static inline double lto_uniform32_f64(lto_xorwow* s)   /* one draw, 32-bit resolution: rocrand_uniform.h:97-100 */
+{
+    uint32_t v = lto_xorwow_next(s);
+    return 2.3283064365386963e-10 + (double)v * 2.3283064365386963e-10;
+}
 static inline float lto_uniform_f32(lto_xorwow* s)
 {
     uint32_t v = lto_xorwow_next(s);
     return 2.3283064365386963e-10f + (float)v * 2.3283064365386963e-10f;
 }
+static inline float lto_uniform32_f32(lto_xorwow* s) { return lto_uniform_f32(s); }
 
 static inline void lto_atomic_add_f64(double* p, double v)
 {
