@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--f32-walk", action="store_true", help="f32 walk arithmetic (default f64, the reference's dtype)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--tally-mode", default="log", choices=["log", "atomic"],
+    ap.add_argument("--tally-mode", default="log", choices=["log", "atomic", "auto"],
                     help="log: deposit log + tile partition + LDS reduce (default); atomic: one global atomic per deposit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -176,7 +176,7 @@ def main():
                        if world > 1 else "single GPU", "device": info["name"], "cus": info["cus"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "walk_kernel + k_log_hist/scan/part/reduce (one job)" if args.tally_mode == "log"
+                         "kernel": "walk_kernel + k_log_scan/part/reduce (one job)" if args.tally_mode == "log"
                          else "walk_kernel", "kernel_ms": kernel_avg_ms,
                          "algorithmic_bytes_per_launch": steps_one_launch * BYTES_PER_STEP[args.tally]},
         }

@@ -221,9 +221,10 @@ class Context:
         self._ck(lib().lt_set_launch_config(self._h, C.c_int(blocks_per_cu), C.c_int(threads_per_block)),
                  "lt_set_launch_config")
 
-    def set_tally_mode(self, mode="atomic", log_bytes=0):
-        """'atomic': global atomics per deposit; 'log': deposit log + tile partition + LDS reduce."""
-        m = {"atomic": 0, "log": 1}[mode] if isinstance(mode, str) else int(mode)
+    def set_tally_mode(self, mode="auto", log_bytes=0):
+        """'atomic': global atomics per deposit; 'log': deposit log + tile partition + LDS reduce;
+        'auto' (default): log for layered slabs, atomic for meshes."""
+        m = {"atomic": 0, "log": 1, "auto": 2}[mode] if isinstance(mode, str) else int(mode)
         self._ck(lib().lt_set_tally_mode(self._h, C.c_int(m), C.c_uint64(int(log_bytes))), "lt_set_tally_mode")
 
     # -- run --------------------------------------------------------------

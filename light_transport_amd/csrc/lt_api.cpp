@@ -71,7 +71,7 @@ struct lt_ctx {
     double src_pos[3] = {0, 0, 0}, src_dir[3] = {0, 0, 1}, src_extra[6] = {0, 0, 0, 0, 0, 0};
     uint32_t max_steps = 1000000;
     uint32_t max_vertices = 0;
-    int tally_mode = 1;                 // 0: global atomics, 1: deposit log + partition + tile reduce (default)
+    int tally_mode = 2;                 // 0: global atomics, 1: deposit log + partition + tile reduce, 2: auto (default)
     size_t log_budget = (size_t)16 << 30; // bytes for the log and its ping-pong copy
     double rec_per_photon = 0.0;        // measured deposit records per photon (sizes the batches)
     size_t log_alloc_records = 0;       // capacity of the log buffers currently allocated
@@ -518,7 +518,10 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     const uint32_t n_tiles = (uint32_t)((c->n_vox() + kTileSize - 1) >> kTileShift);
     const uint32_t n_tiles_pre = (uint32_t)((c->n_vox() + kTileSize - 1) >> kTileShift);
     (void)n_tiles_pre;
-    const bool use_log = c->tally_mode == 1 && !v.table && c->max_vertices == 0 && n_tiles <= 16384 && !std::getenv("LT_DIAG_NO_TALLY");
+    // auto: slab walks are paced by the atomic unit -> log; mesh walks are paced by BVH arithmetic, which hides the
+    // atomics, so the extra log passes would only add time (C4: 101 ms atomic vs 114 ms log)
+    const int mode = c->tally_mode == 2 ? (c->have_mesh ? 0 : 1) : c->tally_mode;
+    const bool use_log = mode == 1 && !v.table && c->max_vertices == 0 && n_tiles <= 16384 && !std::getenv("LT_DIAG_NO_TALLY");
     if (use_log) {
         const size_t rec_bytes = 4 + c->grid_elem();
         size_t budget_records = c->log_budget / (2 * rec_bytes);
@@ -679,7 +682,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
 int lt_set_tally_mode(lt_ctx* c, int mode, uint64_t log_bytes)
 {
     CHECK_CTX(c);
-    if (mode != 0 && mode != 1) return c->fail(LT_E_INVALID, "lt_set_tally_mode: mode must be LT_MODE_ATOMIC or LT_MODE_LOG");
+    if (mode < 0 || mode > 2) return c->fail(LT_E_INVALID, "lt_set_tally_mode: mode must be LT_MODE_ATOMIC, LT_MODE_LOG or LT_MODE_AUTO");
     c->tally_mode = mode;
     if (log_bytes) c->log_budget = (size_t)log_bytes;
     c->rec_per_photon = 0.0;

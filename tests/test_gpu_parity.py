@@ -205,7 +205,7 @@ def test_fixed_point_tally_is_bit_exact(ctx, name, mode):
     prob.apply(ctx, "u64fx")
     ctx.set_tally_mode(mode)
     ctx.launch(n, seed=17); ctx.sync()
-    ctx.set_tally_mode("log")
+    ctx.set_tally_mode("auto")
     fx, c = ctx.read_grid_raw(), ctx.read_counters()
     _, fxo, co = prob.oracle().run(n, seed=17, threads=8, want_fx=True, want_f64=False)
     check_counters(c, co, n)
@@ -523,4 +523,4 @@ def test_log_tally_equals_atomic_tally(ctx):
             b = ctx.read_grid()
             tol = 1e-11 if dtype == "f64" else 2e-3   # f32 sums of ~1e-2 deposits onto ~2e3: order matters at 1e-3
             assert np.abs(a - b).max() <= tol * a.max()
-    ctx.set_tally_mode("log", 0)
+    ctx.set_tally_mode("auto", 0)

@@ -6,7 +6,7 @@ import light_transport_amd as lt
 from tests import scenes as S
 
 ctx = lt.Context(0)
-def run(prob, n, dtype, f32, bpc=0, thr=0, reps=2, label=""):
+def run(prob, n, dtype, f32, bpc=0, thr=0, reps=3, label=""):
     prob.apply(ctx, dtype)
     ctx.set_launch_config(bpc, thr)
     best = 1e9
@@ -36,7 +36,19 @@ if which in ("all", "configs"):
     run(S.slab(n=64, voxel=0.4), 10**7, "f64", False, label="C1-geometry 1e7 64^3")
     run(S.two_layer(n=256, voxel=0.05), 10**7, "f64", False, label="C3 two-layer 256^3")
     run(S.two_layer(n=256, voxel=0.05), 10**7, "f32", True, label="C3 two-layer 256^3")
-    run(S.cornell(256), 10**7, "f64", False, label="C4 cornell+cone mesh 256^3", reps=1)
-    run(S.cornell(256), 10**7, "f32", True, label="C4 cornell+cone mesh 256^3", reps=1)
-    run(S.two_layer(n=512, voxel=0.025), 12500000, "f64", False, label="C5 per-GPU share 512^3", reps=1)
-    run(S.two_layer(n=512, voxel=0.025), 12500000, "f32", True, label="C5 per-GPU share 512^3", reps=1)
+    run(S.cornell(256), 10**7, "f64", False, label="C4 cornell+cone mesh 256^3", reps=3)
+    run(S.cornell(256), 10**7, "f32", True, label="C4 cornell+cone mesh 256^3", reps=3)
+    run(S.two_layer(n=512, voxel=0.025), 12500000, "f64", False, label="C5 per-GPU share 512^3", reps=3)
+    run(S.two_layer(n=512, voxel=0.025), 12500000, "f32", True, label="C5 per-GPU share 512^3", reps=3)
+if which == "modes":
+    for mode in ("atomic", "log"):
+        ctx.set_tally_mode(mode)
+        print("== tally mode", mode, flush=True)
+        run(S.slab(n=64, voxel=0.4), 10**7, "f64", False, label="C1-geometry 1e7 64^3")
+        run(c2, 10**7, "f64", False, label="C2")
+        run(c2, 10**7, "f32", True, label="C2")
+        run(S.two_layer(n=256, voxel=0.05), 10**7, "f64", False, label="C3 two-layer 256^3")
+        run(S.cornell(256), 10**7, "f64", False, label="C4 cornell+cone mesh 256^3")
+        run(S.cornell(256), 10**7, "f32", True, label="C4 cornell+cone mesh 256^3")
+        run(S.two_layer(n=512, voxel=0.025), 12500000, "f64", False, label="C5 per-GPU share 512^3")
+        run(S.two_layer(n=512, voxel=0.025), 12500000, "f32", True, label="C5 per-GPU share 512^3")
