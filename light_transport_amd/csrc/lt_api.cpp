@@ -530,8 +530,10 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         // size the log to the job: measured records per photon when known, else a pilot-sized log
         // (a log that turns out too small only diverts the excess deposits to atomics)
         auto size_log = [&](uint64_t photons_left) -> size_t {
-            double need = c->rec_per_photon > 0.0 ? 1.25 * c->rec_per_photon * (double)photons_left + 1048576.0
-                                                  : 64.0 * 1048576.0;
+            // no measurement yet: assume 256 records per photon (tissue-like media give 100-300); a wrong guess is
+            // corrected after the first batch and an undersized log only diverts the excess deposits to atomics
+            const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 256.0;
+            double need = 1.25 * rate * (double)photons_left + 1048576.0;
             size_t r = need < (double)budget_records ? (size_t)need : budget_records;
             return ((r + kLogChunk - 1) / kLogChunk) * kLogChunk;
         };
@@ -595,9 +597,9 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         int n_batches = 0;
         while (done < n_photons) {
             uint64_t batch = n_photons - done;
-            if (c->rec_per_photon <= 0.0) { if (batch > 65536) batch = 65536; }          // pilot batch measures the record rate
-            else {
-                const double fit = 0.8 * (double)cap_records / c->rec_per_photon;
+            {
+                const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 256.0;
+                const double fit = 0.8 * (double)cap_records / rate;
                 if ((double)batch > fit) batch = fit < 4096.0 ? 4096 : (uint64_t)fit;
             }
             if (done > 0) {   // re-size with the measured record rate (buffers only ever grow)
