@@ -38,7 +38,7 @@ struct DevCounters {
 enum { CW_ABSORBED = 0, CW_LOST, CW_ESC_TOP, CW_ESC_BOT, CW_ESC_MESH, CW_SPECULAR, CW_ROULETTE, CW_CAPPED };
 
 constexpr int kMaxMedia = 32;
-constexpr uint32_t kLogChunk = 4096;    // records per log chunk = records per partition work item
+constexpr uint32_t kLogChunk = 8192;    // records per log chunk = records per partition work item
 constexpr uint32_t kTileShift = 14;     // grid tile = 16384 consecutive voxels (128 KiB of f64 in LDS)
 constexpr uint32_t kTileSize = 1u << kTileShift;
 constexpr int kMaxLayers = 64;

@@ -77,7 +77,7 @@ __global__ void k_log_scan(const uint32_t* hist, uint32_t* tile_base, uint32_t* 
 // ---------------------------------------------------------------------------------------------------------
 // Partition work item: <= 4096 records.  Registers hold the item (16 records per lane), LDS holds the histogram
 // and the digit-sorted copy; each digit's run leaves as one contiguous, coalesced write.
-constexpr int kPartThreads = 256;
+constexpr int kPartThreads = 512;
 constexpr int kPerThread = kLogChunk / kPartThreads;  // 16
 constexpr int kMaxBins = 1024;
 
@@ -85,9 +85,10 @@ template <typename TV, int PASS>
 __global__ void __launch_bounds__(kPartThreads) k_log_part(LogReduceParams L, uint32_t n_items)
 {
     __shared__ uint32_t s_hist[kMaxBins], s_off[kMaxBins + 1], s_gbase[kMaxBins];
-    __shared__ uint32_t s_key[kLogChunk];
-    __shared__ TV s_val[kLogChunk];
     __shared__ uint32_t s_range[3];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // digit-sorted copy of the item (96 KiB at 12 B)
+    TV* s_val = reinterpret_cast<TV*>(s_dyn);
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_dyn + (size_t)kLogChunk * sizeof(TV));
 
     const uint32_t item = blockIdx.x;
     if (item >= n_items) return;
@@ -231,13 +232,23 @@ hipError_t launch_log_scan(const LogReduceParams& L, hipStream_t s)
     return hipGetLastError();
 }
 
+template <typename TV, int PASS> static hipError_t launch_part_t(const LogReduceParams& L, uint32_t n_items, hipStream_t s)
+{
+    const size_t lds = (size_t)kLogChunk * (sizeof(TV) + sizeof(uint32_t));
+    const void* fn = reinterpret_cast<const void*>(&k_log_part<TV, PASS>);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_log_part<TV, PASS>), dim3(n_items), dim3(kPartThreads), lds, s, L, n_items);
+    return hipGetLastError();
+}
 template <int PASS> static hipError_t launch_part(const LogReduceParams& L, uint32_t n_items, hipStream_t s)
 {
     if (n_items == 0) return hipSuccess;
-    if (L.tally == LT_TALLY_F32) hipLaunchKernelGGL((k_log_part<float, PASS>), dim3(n_items), dim3(kPartThreads), 0, s, L, n_items);
-    else if (L.tally == LT_TALLY_F64) hipLaunchKernelGGL((k_log_part<double, PASS>), dim3(n_items), dim3(kPartThreads), 0, s, L, n_items);
-    else hipLaunchKernelGGL((k_log_part<unsigned long long, PASS>), dim3(n_items), dim3(kPartThreads), 0, s, L, n_items);
-    return hipGetLastError();
+    if (L.tally == LT_TALLY_F32) return launch_part_t<float, PASS>(L, n_items, s);
+    if (L.tally == LT_TALLY_F64) return launch_part_t<double, PASS>(L, n_items, s);
+    return launch_part_t<unsigned long long, PASS>(L, n_items, s);
 }
 hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s) { return launch_part<1>(L, L.n_chunks, s); }
 hipError_t launch_log_part2(const LogReduceParams& L, uint32_t n_items, hipStream_t s) { return launch_part<2>(L, n_items, s); }
