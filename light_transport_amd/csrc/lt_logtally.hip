@@ -50,28 +50,69 @@ __global__ void __launch_bounds__(256) k_log_hist(const uint32_t* __restrict__ l
         if (s_h[t]) atomicAdd(&hist[t], s_h[t]);
 }
 
-// one workgroup; n_tiles <= 131072 (2^31 voxels): a serial sweep by one lane is a few microseconds per 10^4 tiles
-__global__ void k_log_scan(const uint32_t* hist, uint32_t* tile_base, uint32_t* cursor1, uint32_t* cursor2,
-                           uint32_t* items2, uint32_t* items_r, uint32_t* totals, uint32_t n_tiles, uint32_t bits2)
+// One workgroup of 1024 lanes; each lane owns a contiguous run of tiles (n_tiles <= 16384 -> <= 16 per lane), a
+// two-level shuffle/LDS scan gives the exclusive prefixes of the record counts and of the reduce work items.
+constexpr int kScanThreads = 1024;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave, uint32_t* total)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t total = 0, ritems = 0;
-    for (uint32_t t = 0; t < n_tiles; t++) {
-        tile_base[t] = total; cursor2[t] = total; total += hist[t];
-        items_r[t] = ritems; ritems += (hist[t] + kReduceSlice - 1) / kReduceSlice;   // hot tiles get several workgroups
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < kScanThreads / 64 ? s_wave[lane] : 0, wi = w;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { uint32_t o = __shfl_up(wi, off, 64); if (lane >= off) wi += o; }
+        if (lane < kScanThreads / 64) s_wave[lane] = wi - w;
+        if (lane == kScanThreads / 64 - 1) *total = wi;
     }
-    tile_base[n_tiles] = total; items_r[n_tiles] = ritems;
-    totals[2] = ritems;
+    __syncthreads();
+    const uint32_t r = s_wave[wave] + incl - v;
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(kScanThreads) k_log_scan(const uint32_t* hist, uint32_t* tile_base, uint32_t* cursor1,
+                                                          uint32_t* cursor2, uint32_t* items2, uint32_t* items_r,
+                                                          uint32_t* totals, uint32_t n_tiles, uint32_t bits2)
+{
+    __shared__ uint32_t s_wave[kScanThreads / 64];
+    __shared__ uint32_t s_tot[2];
+    const uint32_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
+    const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+    uint32_t cnt = 0, rit = 0;
+    for (uint32_t t = t0; t < t1; t++) { const uint32_t h = hist[t]; cnt += h; rit += (h + kReduceSlice - 1) / kReduceSlice; }
+    uint32_t base = block_exclusive_scan(cnt, s_wave, &s_tot[0]);
+    uint32_t rbase = block_exclusive_scan(rit, s_wave, &s_tot[1]);
+    for (uint32_t t = t0; t < t1; t++) {
+        const uint32_t h = hist[t];
+        tile_base[t] = base; cursor2[t] = base; items_r[t] = rbase;
+        base += h; rbase += (h + kReduceSlice - 1) / kReduceSlice;   // hot tiles get several reduce workgroups
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { tile_base[n_tiles] = s_tot[0]; items_r[n_tiles] = s_tot[1]; totals[0] = s_tot[0]; totals[2] = s_tot[1]; }
+    __threadfence();
+    __syncthreads();
+    // level-1 bins: few (<= 128 for 16384 tiles); tile_base of this block's own writes is visible after the fence
     const uint32_t nb1 = (n_tiles + (1u << bits2) - 1) >> bits2;
-    uint32_t items = 0;
-    for (uint32_t b = 0; b < nb1; b++) {
-        const uint32_t t0 = b << bits2, t1 = ((b + 1) << bits2) < n_tiles ? ((b + 1) << bits2) : n_tiles;
-        cursor1[b] = tile_base[t0];
-        items2[b] = items;
-        items += (tile_base[t1] - tile_base[t0] + kLogChunk - 1) / kLogChunk;
+    uint32_t it = 0;
+    for (uint32_t b = threadIdx.x; b < nb1; b += kScanThreads) {
+        const uint32_t a0 = b << bits2, a1 = ((b + 1) << bits2) < n_tiles ? ((b + 1) << bits2) : n_tiles;
+        const uint32_t lo = tile_base[a0], hi = a1 < n_tiles ? tile_base[a1] : s_tot[0];
+        cursor1[b] = lo;
+        it = (hi - lo + kLogChunk - 1) / kLogChunk;
+        items2[b] = it;   // counts for now; prefixed below
     }
-    items2[nb1] = items;
-    totals[0] = total; totals[1] = items;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {   // nb1 <= 1024 when bits2 = 0 (single pass: pass-2 items unused), else <= 128: serial is fine
+        uint32_t run = 0;
+        for (uint32_t b = 0; b < nb1; b++) { const uint32_t c = items2[b]; items2[b] = run; run += c; }
+        items2[nb1] = run; totals[1] = run;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -227,7 +268,7 @@ hipError_t launch_log_hist(const LogReduceParams& L, hipStream_t s)
 
 hipError_t launch_log_scan(const LogReduceParams& L, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_log_scan, dim3(1), dim3(64), 0, s, L.hist, L.tile_base, L.cursor1, L.cursor2, L.items2, L.items_r, L.totals,
+    hipLaunchKernelGGL(k_log_scan, dim3(1), dim3(kScanThreads), 0, s, L.hist, L.tile_base, L.cursor1, L.cursor2, L.items2, L.items_r, L.totals,
                        L.n_tiles, L.bits2);
     return hipGetLastError();
 }
