@@ -83,7 +83,10 @@ struct lt_ctx {
     // device buffers
     DevBuf d_media[2], d_zb[2], d_lm, d_tris[2], d_nodes[2];  // [0]=f64, [1]=f32
     DevBuf d_grid, d_counters, d_head, d_table, d_scratch_in, d_scratch_out, d_scratch_aux;
-    DevBuf d_mats, d_lights, d_r0, d_r1, d_lc, d_img, d_xy, d_vtx, d_vcnt;
+    DevBuf d_mats, d_lights, d_r0, d_r1, d_lc, d_img, d_xy, d_vtx, d_vcnt, d_clear;
+    int cn[3] = {0, 0, 0};
+    double corg[3] = {0, 0, 0}, ccell[3] = {1, 1, 1};
+    bool have_clear = false;
     DevBuf d_log_idx, d_log_val, d_tmp_idx, d_tmp_val, d_log_fill, d_log_meta, d_hist, d_tile_base, d_cursor1, d_cursor2, d_items2, d_items_r;
     bool tables_dirty = true;
     bool timed = false;
@@ -218,6 +221,24 @@ int upload_tables(lt_ctx* c)
         if ((rc = upload(c, c->d_tris[1], t32))) return rc;
         if ((rc = upload(c, c->d_nodes[0], n64))) return rc;
         if ((rc = upload(c, c->d_nodes[1], n32))) return rc;
+        // clearance grid over the root bounds: 64 cells along the longest axis (LT_NO_CLEARANCE=1 disables it)
+        c->have_clear = false;
+        if (!std::getenv("LT_NO_CLEARANCE")) {
+            double ext[3], longest = 0;
+            for (int k = 0; k < 3; k++) { ext[k] = c->nodes[0].hi[k] - c->nodes[0].lo[k]; if (ext[k] > longest) longest = ext[k]; }
+            if (longest > 0 && std::isfinite(longest)) {
+                const double h = longest / 64.0;
+                for (int k = 0; k < 3; k++) {
+                    c->cn[k] = (int)std::ceil(ext[k] / h); if (c->cn[k] < 1) c->cn[k] = 1;
+                    c->ccell[k] = ext[k] > 0 ? ext[k] / c->cn[k] : h; c->corg[k] = c->nodes[0].lo[k];
+                }
+                const size_t cells = (size_t)c->cn[0] * c->cn[1] * c->cn[2];
+                HIP_TRY(c, c->d_clear.ensure(cells * sizeof(float)));
+                HIP_TRY(c, launch_build_clearance(c->d_tris[0].p, (int)t64.size(), (float*)c->d_clear.p, c->cn[0], c->cn[1], c->cn[2],
+                                                  c->corg, c->ccell, c->stream));
+                c->have_clear = true;
+            }
+        }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->tables_dirty = false;
@@ -298,7 +319,7 @@ int lt_destroy(lt_ctx* c)
     c->d_lm.release(); c->d_grid.release(); c->d_counters.release(); c->d_head.release(); c->d_table.release();
     c->d_scratch_in.release(); c->d_scratch_out.release(); c->d_scratch_aux.release();
     c->d_mats.release(); c->d_lights.release(); c->d_r0.release(); c->d_r1.release(); c->d_lc.release();
-    c->d_img.release(); c->d_xy.release(); c->d_vtx.release(); c->d_vcnt.release();
+    c->d_img.release(); c->d_xy.release(); c->d_vtx.release(); c->d_vcnt.release(); c->d_clear.release();
     c->d_log_idx.release(); c->d_log_val.release(); c->d_tmp_idx.release(); c->d_tmp_val.release(); c->d_log_fill.release();
     c->d_log_meta.release(); c->d_hist.release(); c->d_tile_base.release(); c->d_cursor1.release(); c->d_cursor2.release();
     c->d_items2.release(); c->d_items_r.release();
@@ -485,6 +506,10 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     P.table = (const double*)c->d_table.p; P.table_steps = table_steps;
     P.max_steps = c->max_steps;
     P.counters = (DevCounters*)c->d_counters.p;
+    if (c->have_mesh && c->have_clear) {
+        P.clear = (const float*)c->d_clear.p; P.cnx = c->cn[0]; P.cny = c->cn[1]; P.cnz = c->cn[2];
+        for (int k = 0; k < 3; k++) { P.corg[k] = c->corg[k]; P.cinv[k] = 1.0 / c->ccell[k]; }
+    }
     c->captured_photons = 0;
     if (c->max_vertices > 0) {
         const size_t vb = (size_t)n_photons * c->max_vertices * sizeof(lt_vertex);

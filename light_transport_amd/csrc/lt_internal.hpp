@@ -76,6 +76,11 @@ struct WalkParams {
     uint32_t log_cap_chunks;
     uint32_t* log_hist;   // [log_n_tiles] records per grid tile, accumulated by the walk (LDS histogram per workgroup)
     uint32_t log_n_tiles;
+    // clearance grid (mesh scenes; null = off): conservative lower bound of the distance from any point of a cell
+    // to any triangle -- a hop shorter than that cannot hit, so the BVH query is skipped
+    const float* clear;
+    int cnx, cny, cnz;
+    double corg[3], cinv[3];
     // light sub-path capture (null = off)
     lt_vertex* vertices;
     uint32_t* vertex_counts;
@@ -115,6 +120,8 @@ struct RenderParams {
     const int32_t* light_choice;
     double* image;
 };
+hipError_t launch_build_clearance(const void* tris_f64, int n_tris, float* clear, int nx, int ny, int nz,
+                                  const double org[3], const double cell[3], hipStream_t s);
 hipError_t launch_render_surface(const RenderParams& P, hipStream_t s);
 
 // log-structured tally pipeline (all on stream s)

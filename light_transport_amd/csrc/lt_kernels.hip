@@ -519,10 +519,10 @@ constexpr unsigned kPacket = 64;  // photon ids taken from the global queue per 
 #define LT_F64_WAVES 3
 #endif
 #ifndef LT_F32_WAVES
-#define LT_F32_WAVES 4
+#define LT_F32_WAVES 5
 #endif
 template <typename R, int GEOM, bool TABLE, int TALLY>
-__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? LT_F64_WAVES : LT_F32_WAVES)) walk_kernel(const WalkParams P)
+__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? LT_F64_WAVES : (GEOM == 0 ? LT_F32_WAVES : 4))) walk_kernel(const WalkParams P)
 {
     constexpr bool MESH = GEOM != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -709,9 +709,22 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? LT_F64_WAVES : LT_F32_W
                     if (uz > 0) tb = (s_zb[cur + 1] - pz) / uz;
                     else if (uz < 0) tb = (s_zb[cur] - pz) / uz;
                 } else {
-                    R o[3] = {px, py, pz}, d[3] = {ux, uy, uz}, th;
-                    nearest_bvh(s_tris, s_nodes, P.n_nodes, o, d, s, hit_tri, th);
-                    if (hit_tri >= 0) tb = th;
+                    // clearance grid: every triangle is farther than `c` from every point of this cell, so a hop of
+                    // length s < c ends before any surface and the traversal is skipped (same result, no query)
+                    bool query = true;
+                    if (P.clear) {
+                        const R cx = (px - (R)P.corg[0]) * (R)P.cinv[0], cy = (py - (R)P.corg[1]) * (R)P.cinv[1],
+                                cz = (pz - (R)P.corg[2]) * (R)P.cinv[2];
+                        if (cx >= 0 && cx < (R)P.cnx && cy >= 0 && cy < (R)P.cny && cz >= 0 && cz < (R)P.cnz) {
+                            const float c = P.clear[((size_t)(int)cz * P.cny + (int)cy) * P.cnx + (int)cx];
+                            query = !(s < (R)c);
+                        }
+                    }
+                    if (query) {
+                        R o[3] = {px, py, pz}, d[3] = {ux, uy, uz}, th;
+                        nearest_bvh(s_tris, s_nodes, P.n_nodes, o, d, s, hit_tri, th);
+                        if (hit_tri >= 0) tb = th;
+                    }
                 }
                 const bool at_boundary = MESH ? (hit_tri >= 0) : (tb <= s);
                 if (!at_boundary && !(s < inf)) {
@@ -992,6 +1005,66 @@ __global__ void k_grid_to_f64(const void* grid, int tally, size_t n, double* out
         else if (tally == LT_TALLY_F64) out[i] = reinterpret_cast<const double*>(grid)[i];
         else out[i] = (double)reinterpret_cast<const unsigned long long*>(grid)[i] * (1.0 / LT_FX_SCALE);
     }
+}
+
+// ---------------------------------------------------------------------------
+// clearance grid builder: per cell, min over triangles of the distance from the cell centre to the triangle
+// (closest-point-on-triangle by regions), minus the half diagonal of the cell, shrunk by a safety margin
+// ---------------------------------------------------------------------------
+LT_DEV double point_tri_dist2(const double* p, const TriD<double>& T)
+{
+    const double ab[3] = {T.ab[0], T.ab[1], T.ab[2]}, ac[3] = {T.ac[0], T.ac[1], T.ac[2]};
+    const double ap[3] = {p[0] - T.a[0], p[1] - T.a[1], p[2] - T.a[2]};
+    const double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+    double q[3];
+    if (d1 <= 0 && d2 <= 0) { q[0] = 0; q[1] = 0; q[2] = 0; }                       // vertex A
+    else {
+        const double bp[3] = {ap[0] - ab[0], ap[1] - ab[1], ap[2] - ab[2]};
+        const double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+        const double cp[3] = {ap[0] - ac[0], ap[1] - ac[1], ap[2] - ac[2]};
+        const double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+        const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+        if (d3 >= 0 && d4 <= d3) { q[0] = ab[0]; q[1] = ab[1]; q[2] = ab[2]; }   // vertex B
+        else if (vc <= 0 && d1 >= 0 && d3 <= 0) { const double v = d1 / (d1 - d3); for (int k = 0; k < 3; k++) q[k] = v * ab[k]; }
+        else if (d6 >= 0 && d5 <= d6) { q[0] = ac[0]; q[1] = ac[1]; q[2] = ac[2]; }  // vertex C
+        else if (vb <= 0 && d2 >= 0 && d6 <= 0) { const double w = d2 / (d2 - d6); for (int k = 0; k < 3; k++) q[k] = w * ac[k]; }
+        else if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+            const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+            for (int k = 0; k < 3; k++) q[k] = ab[k] + w * (ac[k] - ab[k]);
+        } else {
+            const double den = 1.0 / (va + vb + vc), v = vb * den, w = vc * den;
+            for (int k = 0; k < 3; k++) q[k] = v * ab[k] + w * ac[k];
+        }
+    }
+    const double e[3] = {ap[0] - q[0], ap[1] - q[1], ap[2] - q[2]};
+    return dot3(e, e);
+}
+
+__global__ void k_build_clearance(const TriD<double>* tris, int n_tris, float* clear, int nx, int ny, int nz,
+                                  double ox, double oy, double oz, double hx, double hy, double hz)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nx * ny * nz) return;
+    const int ix = (int)(i % nx), iy = (int)((i / nx) % ny), iz = (int)(i / ((size_t)nx * ny));
+    const double p[3] = {ox + (ix + 0.5) * hx, oy + (iy + 0.5) * hy, oz + (iz + 0.5) * hz};
+    double best = __builtin_huge_val();
+    for (int t = 0; t < n_tris; t++) { const double d2 = point_tri_dist2(p, tris[t]); best = d2 < best ? d2 : best; }
+    const double half_diag = 0.5 * ::sqrt(hx * hx + hy * hy + hz * hz);
+    double c = (::sqrt(best) - half_diag) * (1.0 - 1e-6) - 1e-7 * (hx + hy + hz);   // strictly conservative
+    float f = c > 0 ? (float)c : 0.0f;
+    if ((double)f > c && f > 0) f = __uint_as_float(__float_as_uint(f) - 1u);      // round toward zero
+    clear[i] = f;
+}
+
+hipError_t launch_build_clearance(const void* tris_f64, int n_tris, float* clear, int nx, int ny, int nz,
+                                  const double org[3], const double cell[3], hipStream_t s)
+{
+    const size_t n = (size_t)nx * ny * nz;
+    if (n == 0 || n_tris <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_build_clearance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const TriD<double>*>(tris_f64), n_tris, clear, nx, ny, nz, org[0], org[1], org[2],
+                       cell[0], cell[1], cell[2]);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
