@@ -555,9 +555,9 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         // size the log to the job: measured records per photon when known, else a pilot-sized log
         // (a log that turns out too small only diverts the excess deposits to atomics)
         auto size_log = [&](uint64_t photons_left) -> size_t {
-            // no measurement yet: assume 256 records per photon (tissue-like media give 100-300); a wrong guess is
+            // no measurement yet: assume 200 records per photon (tissue-like media give 100-300); a wrong guess is
             // corrected after the first batch and an undersized log only diverts the excess deposits to atomics
-            const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 256.0;
+            const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 200.0;
             double need = 1.25 * rate * (double)photons_left + 1048576.0;
             size_t r = need < (double)budget_records ? (size_t)need : budget_records;
             return ((r + kLogChunk - 1) / kLogChunk) * kLogChunk;
@@ -623,7 +623,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         while (done < n_photons) {
             uint64_t batch = n_photons - done;
             {
-                const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 256.0;
+                const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 200.0;
                 const double fit = 0.8 * (double)cap_records / rate;
                 if ((double)batch > fit) batch = fit < 4096.0 ? 4096 : (uint64_t)fit;
             }
