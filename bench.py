@@ -115,7 +115,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kernel_ms, steps_per_launch = [], []
+    kernel_ms, steps_per_launch, stages = [], [], []
 
     def one_step(seed):
         ctx.zero_tally()
@@ -133,6 +133,9 @@ def main():
     for k in range(args.steps):
         one_step(k)
         kernel_ms.append(ctx.last_kernel_ms())
+        st = ctx.last_log_stages()
+        if st is not None and st["batches"] == 1:
+            stages.append(st)
         # photon-steps of this launch: rank 0 holds the reduced sum, other ranks their own
         c = ctx.read_counters()
         steps_per_launch.append(c["steps"])
@@ -180,6 +183,22 @@ def main():
                          else "walk_kernel", "kernel_ms": kernel_avg_ms,
                          "algorithmic_bytes_per_launch": steps_one_launch * BYTES_PER_STEP[args.tally]},
         }
+        if stages:
+            # per-kernel rooflines of the job, live from HIP events on the ctx stream (one batch per job)
+            rec = float(np.mean([x["records"] for x in stages]))
+            rb = 4 + {"f32": 4, "f64": 8, "u64fx": 8}[args.tally]          # bytes per deposit record
+            w, p_, r_ = (float(np.mean([x[k] for x in stages])) for k in ("walk_ms", "partition_ms", "reduce_ms"))
+            out["roofline"]["kernels"] = [
+                {"kernel": "walk_kernel", "ms": w, "bound": "valu",
+                 "note": "405 VALU instr per photon-step (PMC SQ_INSTS_VALU), 3 waves/SIMD; writes the %.1f GB deposit log" % (rec * rb / 1e9),
+                 "photon_steps_per_sec": steps_one_launch / (w * 1e-3)},
+                {"kernel": "k_log_part", "ms": p_, "bound": "hbm", "achieved": 2 * rb * rec / (p_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": 2 * rb * rec / (p_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "note": "algorithmic: every record read once and written once"},
+                {"kernel": "k_log_reduce", "ms": r_, "bound": "hbm", "achieved": rb * rec / (r_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": rb * rec / (r_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "note": "algorithmic: every record read once"}]
+            out["roofline"]["deposit_records_per_launch"] = rec
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

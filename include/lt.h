@@ -163,6 +163,10 @@ int lt_sync(lt_ctx* ctx);
  * lt_launch (HIP events on the ctx stream); valid after lt_sync. */
 int lt_last_kernel_ms(lt_ctx* ctx, double* ms);
 int lt_zero_tally(lt_ctx* ctx); /* zero grid + counters (async)           */
+/* device milliseconds of the stages of the LAST batch of the last log-mode
+ * lt_launch: [0] walk kernel, [1] counts readback + scan, [2] partition
+ * pass(es), [3] tile reduce; deposit records and batches of that launch. */
+int lt_last_log_stages(lt_ctx* ctx, double ms_out[4], uint64_t* records, uint64_t* batches);
 
 /* ---- readback ---------------------------------------------------------- */
 /* blocking D2H of the raw tally ([nz][ny][nx], dtype as set) */

@@ -28,7 +28,7 @@ SYMBOLS = [
     "lt_grid_device_ptr", "lt_counters_device_ptr", "lt_stream", "lt_reduce_grid", "lt_intersect_rays",
     "lt_triangle_intersect", "lt_intersect_bounds", "lt_eval", "lt_rng_raw", "lt_device_info",
     "lt_set_surface_materials", "lt_set_lights", "lt_render_surface", "lt_set_vertex_capture", "lt_read_vertices",
-    "lt_set_tally_mode",
+    "lt_set_tally_mode", "lt_last_log_stages",
 ]
 
 # lt_vertex as a NumPy record (72 bytes, same layout as the C struct)
@@ -247,6 +247,14 @@ class Context:
         ms = C.c_double()
         self._ck(lib().lt_last_kernel_ms(self._h, C.byref(ms)), "lt_last_kernel_ms")
         return ms.value
+
+    def last_log_stages(self):
+        """dict(walk_ms, scan_ms, partition_ms, reduce_ms, records, batches) of the last log-mode launch, or None."""
+        ms = (C.c_double * 4)()
+        rec, bat = C.c_uint64(), C.c_uint64()
+        if lib().lt_last_log_stages(self._h, ms, C.byref(rec), C.byref(bat)) != 0:
+            return None
+        return dict(walk_ms=ms[0], scan_ms=ms[1], partition_ms=ms[2], reduce_ms=ms[3], records=rec.value, batches=bat.value)
 
     def zero_tally(self):
         self._ck(lib().lt_zero_tally(self._h), "lt_zero_tally")

@@ -51,6 +51,9 @@ struct lt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries of the last log-mode batch
+    bool stages_valid = false;
+    uint64_t last_records = 0, last_batches = 0;
     std::string err;
     hipDeviceProp_t prop;
 
@@ -298,6 +301,7 @@ int lt_create(lt_ctx** out, int device_id)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    for (int k = 0; k < 6 && e == hipSuccess; k++) e = hipEventCreate(&c->evs[k]);
     if (e == hipSuccess) e = c->d_counters.ensure(sizeof(DevCounters));
     if (e == hipSuccess) e = c->d_head.ensure(sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), c->stream);
@@ -325,6 +329,7 @@ int lt_destroy(lt_ctx* c)
     c->d_items2.release(); c->d_items_r.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int k = 0; k < 6; k++) if (c->evs[k]) (void)hipEventDestroy(c->evs[k]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LT_OK;
@@ -646,7 +651,9 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
             HIP_TRY(c, hipMemsetAsync(meta, 0, 32, c->stream));
             HIP_TRY(c, hipMemsetAsync(c->d_hist.p, 0, (size_t)n_tiles * 4, c->stream));
             if (diag) HIP_TRY(c, hipEventRecord(te[0], c->stream));
+            HIP_TRY(c, hipEventRecord(c->evs[0], c->stream));
             HIP_TRY(c, launch_walk(P, v, cfg, c->stream));
+            HIP_TRY(c, hipEventRecord(c->evs[1], c->stream));
             if (diag) HIP_TRY(c, hipEventRecord(te[7], c->stream));
             uint32_t h[5] = {0, 0, 0, 0, 0};
             HIP_TRY(c, hipMemcpyAsync(h, meta, 4, hipMemcpyDeviceToHost, c->stream));
@@ -656,17 +663,22 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
             if (diag) HIP_TRY(c, hipEventRecord(te[1], c->stream));
             if (diag) HIP_TRY(c, hipEventRecord(te[2], c->stream));   // (tile histogram now comes from the walk)
             HIP_TRY(c, launch_log_scan(L, c->stream));
+            HIP_TRY(c, hipEventRecord(c->evs[2], c->stream));
             if (diag) HIP_TRY(c, hipEventRecord(te[3], c->stream));
             HIP_TRY(c, hipMemcpyAsync(h + 2, meta + 2, 12, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (diag) HIP_TRY(c, hipEventRecord(te[3], c->stream));
             HIP_TRY(c, launch_log_part1(L, c->stream));
+            HIP_TRY(c, hipEventRecord(c->evs[3], c->stream));
             if (diag) HIP_TRY(c, hipEventRecord(te[4], c->stream));
             LogReduceParams Lr = L;
             if (bits2 == 0) { Lr.log_idx = L.tmp_idx; Lr.log_val = L.tmp_val; }   // single pass: tiles are final in tmp
             else HIP_TRY(c, launch_log_part2(L, h[3], c->stream));
             if (diag) HIP_TRY(c, hipEventRecord(te[5], c->stream));
+            HIP_TRY(c, hipEventRecord(c->evs[4], c->stream));
             HIP_TRY(c, launch_log_reduce(Lr, h[4], c->stream));
+            HIP_TRY(c, hipEventRecord(c->evs[5], c->stream));
+            c->last_records = h[2];
             if (diag) {
                 HIP_TRY(c, hipEventRecord(te[6], c->stream));
                 HIP_TRY(c, hipEventSynchronize(te[6]));
@@ -689,6 +701,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
             done += batch;
         }
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        c->stages_valid = true; c->last_batches = (uint64_t)n_batches;
         if (diag) {
             std::fprintf(stderr, "[lt log] stages ms: walk %.2f hist %.2f scan %.2f part1 %.2f part2 %.2f reduce %.2f\n",
                          stage[0], stage[1], stage[2], stage[3], stage[4], stage[5]);
@@ -698,6 +711,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         return LT_OK;
     }
 
+    c->stages_valid = false;
     HIP_TRY(c, hipMemsetAsync(c->d_head.p, 0, sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, launch_walk(P, v, cfg, c->stream));
@@ -734,6 +748,23 @@ int lt_last_kernel_ms(lt_ctx* c, double* ms)
     float f = 0;
     HIP_TRY(c, hipEventElapsedTime(&f, c->ev0, c->ev1));
     *ms = (double)f;
+    return LT_OK;
+}
+
+int lt_last_log_stages(lt_ctx* c, double ms_out[4], uint64_t* records, uint64_t* batches)
+{
+    CHECK_CTX(c);
+    if (!ms_out) return c->fail(LT_E_INVALID, "lt_last_log_stages: null output");
+    if (!c->stages_valid) return c->fail(LT_E_STATE, "lt_last_log_stages: the last launch did not use the log tally");
+    BIND(c);
+    HIP_TRY(c, hipEventSynchronize(c->evs[5]));
+    float f;
+    HIP_TRY(c, hipEventElapsedTime(&f, c->evs[0], c->evs[1])); ms_out[0] = f;   // walk
+    HIP_TRY(c, hipEventElapsedTime(&f, c->evs[1], c->evs[2])); ms_out[1] = f;   // counts readback + scan
+    HIP_TRY(c, hipEventElapsedTime(&f, c->evs[2], c->evs[4])); ms_out[2] = f;   // partition pass(es)
+    HIP_TRY(c, hipEventElapsedTime(&f, c->evs[4], c->evs[5])); ms_out[3] = f;   // tile reduce
+    if (records) *records = c->last_records;
+    if (batches) *batches = c->last_batches;
     return LT_OK;
 }
 
