@@ -545,7 +545,9 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     if (cfg.blocks < 1) cfg.blocks = 1;
 
     // ---- log-structured tally: walk -> deposit log -> partition by grid tile -> LDS tile reduce, in batches
-    const uint32_t n_tiles = (uint32_t)((c->n_vox() + kTileSize - 1) >> kTileShift);
+    const uint32_t ntx = ((uint32_t)c->nx + 31u) >> kTileBX, nty = ((uint32_t)c->ny + 31u) >> kTileBY,
+                   ntz = ((uint32_t)c->nz + 15u) >> kTileBZ;
+    const uint32_t n_tiles = ntx * nty * ntz;   // 32 x 32 x 16-voxel blocks
     const uint32_t n_tiles_pre = (uint32_t)((c->n_vox() + kTileSize - 1) >> kTileShift);
     (void)n_tiles_pre;
     // auto: slab walks are paced by the atomic unit -> log; mesh walks are paced by BVH arithmetic, which hides the
@@ -601,7 +603,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         uint32_t* meta = (uint32_t*)c->d_log_meta.p;   // [0] next chunk, [2..3] totals
         P.log_idx = (uint32_t*)c->d_log_idx.p; P.log_val = c->d_log_val.p; P.log_fill = (uint32_t*)c->d_log_fill.p;
         P.log_next = meta; P.log_cap_chunks = cap_chunks;
-        P.log_hist = (uint32_t*)c->d_hist.p; P.log_n_tiles = n_tiles;
+        P.log_hist = (uint32_t*)c->d_hist.p; P.log_n_tiles = n_tiles; P.log_ntx = ntx; P.log_nty = nty;
         cfg.lds_bytes = walk_lds_bytes(v, P.n_media, P.n_layers, P.n_tris, P.n_nodes, n_tiles);
         {
             const int res2 = walk_max_blocks_per_cu(v, cfg.threads, cfg.lds_bytes);
@@ -617,6 +619,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         L.cursor1 = (uint32_t*)c->d_cursor1.p; L.cursor2 = (uint32_t*)c->d_cursor2.p; L.items2 = (uint32_t*)c->d_items2.p; L.items_r = (uint32_t*)c->d_items_r.p;
         L.totals = meta + 2; L.n_tiles = n_tiles; L.bits2 = bits2;
         L.grid = c->d_grid.p; L.n_vox = c->n_vox(); L.tally = c->tally;
+        L.nx = (uint32_t)c->nx; L.ny = (uint32_t)c->ny; L.nz = (uint32_t)c->nz; L.ntx = ntx; L.nty = nty;
 
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         uint64_t done = 0;

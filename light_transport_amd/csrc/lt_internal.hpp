@@ -39,8 +39,12 @@ enum { CW_ABSORBED = 0, CW_LOST, CW_ESC_TOP, CW_ESC_BOT, CW_ESC_MESH, CW_SPECULA
 
 constexpr int kMaxMedia = 32;
 constexpr uint32_t kLogChunk = 8192;    // records per log chunk = records per partition work item
-constexpr uint32_t kTileShift = 14;     // grid tile = 16384 consecutive voxels (128 KiB of f64 in LDS)
+constexpr uint32_t kTileShift = 14;     // grid tile = 32 x 32 x 16 voxels = 16384 (128 KiB of f64 in LDS)
 constexpr uint32_t kTileSize = 1u << kTileShift;
+// Deposit records carry a TILED voxel index: (tile id << 14) | (z&15)<<10 | (y&31)<<5 | (x&31), tile id =
+// (tz * nty + ty) * ntx + tx.  3-D blocks follow the compact photon cloud, so far fewer tiles are active than with
+// slabs of consecutive linear indices and the partition pass writes longer contiguous runs.
+constexpr uint32_t kTileBX = 5, kTileBY = 5, kTileBZ = 4;
 constexpr int kMaxLayers = 64;
 
 struct WalkParams {
@@ -75,7 +79,7 @@ struct WalkParams {
     uint32_t* log_next;   // next free chunk
     uint32_t log_cap_chunks;
     uint32_t* log_hist;   // [log_n_tiles] records per grid tile, accumulated by the walk (LDS histogram per workgroup)
-    uint32_t log_n_tiles;
+    uint32_t log_n_tiles, log_ntx, log_nty;
     // clearance grid (mesh scenes; null = off): conservative lower bound of the distance from any point of a cell
     // to any triangle -- a hop shorter than that cannot hit, so the BVH query is skipped
     const float* clear;
@@ -137,6 +141,7 @@ struct LogReduceParams {
     uint32_t* totals;                          // [3]: total records, pass-2 items, reduce items
     uint32_t n_tiles, bits2;                   // level-2 digit width; level-1 bins = ceil(n_tiles >> bits2)
     void* grid; size_t n_vox; int tally;
+    uint32_t nx, ny, nz, ntx, nty;             // grid shape and tile counts along x, y (tiled record index)
 };
 hipError_t launch_log_hist(const LogReduceParams& L, hipStream_t s);
 hipError_t launch_log_scan(const LogReduceParams& L, hipStream_t s);

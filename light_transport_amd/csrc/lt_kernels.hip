@@ -495,8 +495,14 @@ LT_DEV void emit_deposit(const WalkParams& P, bool has, unsigned idx, typename T
         if (c < P.log_cap_chunks) { lg_chunk = c; lg_cur = c * kLogChunk; lg_end = lg_cur + kLogChunk; }
         else { lg_chunk = 0xffffffffu; lg_cur = lg_end = 0; }
     }
-    if (lg_chunk == 0xffffffffu) {  // log exhausted
-        if (has) tally_add<TALLY>(P.grid, idx, val);
+    if (lg_chunk == 0xffffffffu) {  // log exhausted: back to the linear voxel index and a global atomic
+        if (has) {
+            const unsigned tile = idx >> kTileShift, tx = tile % P.log_ntx, ty = (tile / P.log_ntx) % P.log_nty,
+                           tz = tile / (P.log_ntx * P.log_nty);
+            const unsigned vx = (tx << kTileBX) | (idx & 31u), vy = (ty << kTileBY) | ((idx >> 5) & 31u),
+                           vz = (tz << kTileBZ) | ((idx >> 10) & 15u);
+            tally_add<TALLY>(P.grid, (vz * (unsigned)P.ny + vy) * (unsigned)P.nx + vx, val);
+        }
         return;
     }
     if (has) {
@@ -781,7 +787,11 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? LT_F64_WAVES : (GEOM ==
                     const R dw = w * Mp->absorb;
                     const R fx = (px - gx0) * ivx, fy = (py - gy0) * ivy, fz = (pz - gz0) * ivz;
                     if (fx >= 0 && fx < fnx && fy >= 0 && fy < fny && fz >= 0 && fz < fnz) {
-                        const unsigned idx = ((unsigned)(int)fz * (unsigned)P.ny + (unsigned)(int)fy) * (unsigned)P.nx + (unsigned)(int)fx;
+                        const unsigned vx = (unsigned)(int)fx, vy = (unsigned)(int)fy, vz = (unsigned)(int)fz;
+                        const unsigned idx = P.log_idx   // log mode: tiled index (see kTileBX); atomic mode: linear index
+                            ? (((((vz >> kTileBZ) * P.log_nty + (vy >> kTileBY)) * P.log_ntx + (vx >> kTileBX)) << kTileShift)
+                               | ((vz & 15u) << 10) | ((vy & 31u) << 5) | (vx & 31u))
+                            : (vz * (unsigned)P.ny + vy) * (unsigned)P.nx + vx;
                         const TV q = tally_quantum<TALLY, R>(dw);
                         if (idx == pend_idx) pend_val += q;
                         else { f_idx = pend_idx; f_val = pend_val; pend_idx = idx; pend_val = q; }

@@ -4,7 +4,7 @@
 // (~16e9 requests/s) while its arithmetic alone would sustain 4x that.  MI355X has 288 GB of
 // HBM at ~6 TB/s of streaming bandwidth, so the deposits are instead WRITTEN as a coalesced log
 // (lt_kernels.hip: emit_deposit) and reduced here with streaming passes only:
-//   k_log_hist   records per grid tile (tile = 16384 consecutive voxels = one LDS-sized slab of the grid)
+//   (walk)       records per grid tile, LDS histogram (tile = 32 x 32 x 16 voxels = one LDS-sized block of the grid)
 //   k_log_scan   exclusive prefix -> where every tile's records will live; level-1 / level-2 cursors
 //   k_log_part   LSD-free two-level radix partition by tile id (pass 1: high digit, pass 2: low digit);
 //                a workgroup sorts 4096 records by digit in LDS and writes each digit's run contiguously
@@ -245,12 +245,14 @@ __global__ void __launch_bounds__(kReduceThreads) k_log_reduce(LogReduceParams L
     for (; k < hi; k += kReduceThreads) lds_add(&s_tile[idx[k] & (kTileSize - 1)], (AT)val[k]);
     __syncthreads();
     TV* grid = reinterpret_cast<TV*>(L.grid);
-    const size_t base = (size_t)t << kTileShift;
+    const uint32_t tx = t % L.ntx, ty = (t / L.ntx) % L.nty, tz = t / (L.ntx * L.nty);
     for (uint32_t v = threadIdx.x; v < kTileSize; v += kReduceThreads) {
         const TV a = (TV)s_tile[v];
-        if (a != 0 && base + v < L.n_vox) {
-            if (shared_tile) __hip_atomic_fetch_add(&grid[base + v], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else grid[base + v] += a;   // exclusive owner of this tile: plain read-add-write
+        const uint32_t vx = (tx << kTileBX) | (v & 31u), vy = (ty << kTileBY) | ((v >> 5) & 31u), vz = (tz << kTileBZ) | (v >> 10);
+        if (a != 0 && vx < L.nx && vy < L.ny && vz < L.nz) {
+            TV* dst = &grid[((size_t)vz * L.ny + vy) * L.nx + vx];
+            if (shared_tile) __hip_atomic_fetch_add(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst += a;   // exclusive owner of this tile: plain read-add-write
         }
     }
 }
