@@ -104,6 +104,8 @@ def main():
     ctx.set_tally_mode(args.tally_mode)
     if args.blocks_per_cu or args.threads:
         ctx.set_launch_config(args.blocks_per_cu, args.threads)
+    if args.tally_mode != "atomic":
+        ctx.reserve_log(args.photons)   # scratch allocation is set-up, not part of a step (matters when --warmup 0)
     info = ctx.device_info()
     per_gpu = args.photons
     offset = rank * per_gpu     # disjoint id ranges; streams depend on (seed, id) only

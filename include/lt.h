@@ -144,6 +144,8 @@ int lt_set_launch_config(lt_ctx* ctx, int blocks_per_cu, int threads_per_block);
 #define LT_MODE_LOG 1
 #define LT_MODE_AUTO 2 /* default: LOG for layered slabs (atomic-unit bound), ATOMIC for meshes (BVH-arithmetic bound) */
 int lt_set_tally_mode(lt_ctx* ctx, int mode, uint64_t log_bytes);
+/* optional: allocate the deposit log for launches of up to n_photons now (otherwise the first launch does it) */
+int lt_reserve_log(lt_ctx* ctx, uint64_t n_photons);
 
 /* ---- run --------------------------------------------------------------- */
 /* role of render_scene (path_tracing_fix1.py:139-169): trace photons

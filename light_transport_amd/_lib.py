@@ -28,7 +28,7 @@ SYMBOLS = [
     "lt_grid_device_ptr", "lt_counters_device_ptr", "lt_stream", "lt_reduce_grid", "lt_intersect_rays",
     "lt_triangle_intersect", "lt_intersect_bounds", "lt_eval", "lt_rng_raw", "lt_device_info",
     "lt_set_surface_materials", "lt_set_lights", "lt_render_surface", "lt_set_vertex_capture", "lt_read_vertices",
-    "lt_set_tally_mode", "lt_last_log_stages",
+    "lt_set_tally_mode", "lt_last_log_stages", "lt_reserve_log",
 ]
 
 # lt_vertex as a NumPy record (72 bytes, same layout as the C struct)
@@ -226,6 +226,9 @@ class Context:
         'auto' (default): log for layered slabs, atomic for meshes."""
         m = {"atomic": 0, "log": 1, "auto": 2}[mode] if isinstance(mode, str) else int(mode)
         self._ck(lib().lt_set_tally_mode(self._h, C.c_int(m), C.c_uint64(int(log_bytes))), "lt_set_tally_mode")
+
+    def reserve_log(self, n_photons):
+        self._ck(lib().lt_reserve_log(self._h, C.c_uint64(int(n_photons))), "lt_reserve_log")
 
     # -- run --------------------------------------------------------------
     def launch(self, n_photons, seed=0, photon_offset=0, rng_table=None, f32_walk=False):

@@ -723,6 +723,26 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     return LT_OK;
 }
 
+int lt_reserve_log(lt_ctx* c, uint64_t n_photons)
+{
+    CHECK_CTX(c);
+    if (!c->have_grid) return c->fail(LT_E_STATE, "lt_reserve_log: lt_set_grid first");
+    BIND(c);
+    const size_t rec_bytes = 4 + c->grid_elem();
+    size_t budget_records = c->log_budget / (2 * rec_bytes);
+    if (budget_records > 0xFFF00000ull) budget_records = 0xFFF00000ull;
+    const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 200.0;
+    double need = 1.25 * rate * (double)n_photons + 1048576.0;
+    size_t r = need < (double)budget_records ? (size_t)need : budget_records;
+    r = ((r + kLogChunk - 1) / kLogChunk) * kLogChunk;
+    if (c->log_alloc_elem == (int)c->grid_elem() && r <= c->log_alloc_records) return LT_OK;
+    HIP_TRY(c, c->d_log_idx.ensure(r * 4)); HIP_TRY(c, c->d_tmp_idx.ensure(r * 4));
+    HIP_TRY(c, c->d_log_val.ensure(r * c->grid_elem())); HIP_TRY(c, c->d_tmp_val.ensure(r * c->grid_elem()));
+    HIP_TRY(c, c->d_log_fill.ensure((r / kLogChunk) * 4));
+    c->log_alloc_records = r; c->log_alloc_elem = (int)c->grid_elem();
+    return LT_OK;
+}
+
 int lt_set_tally_mode(lt_ctx* c, int mode, uint64_t log_bytes)
 {
     CHECK_CTX(c);
