@@ -553,7 +553,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     // auto: slab walks are paced by the atomic unit -> log; mesh walks are paced by BVH arithmetic, which hides the
     // atomics, so the extra log passes would only add time (C4: 101 ms atomic vs 114 ms log)
     const int mode = c->tally_mode == 2 ? (c->have_mesh ? 0 : 1) : c->tally_mode;
-    const bool use_log = mode == 1 && !v.table && c->max_vertices == 0 && n_tiles <= 16384 && !std::getenv("LT_DIAG_NO_TALLY");
+    bool use_log = mode == 1 && !v.table && c->max_vertices == 0 && n_tiles <= 16384 && !std::getenv("LT_DIAG_NO_TALLY");
     if (use_log) {
         const size_t rec_bytes = 4 + c->grid_elem();
         size_t budget_records = c->log_budget / (2 * rec_bytes);
@@ -589,7 +589,18 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
             if ((e = c->d_tmp_val.ensure(cap_records * c->grid_elem())) != hipSuccess) return e;
             return c->d_log_fill.ensure((size_t)cap_chunks * 4);
         };
-        HIP_TRY(c, ensure_log());
+        if (ensure_log() != hipSuccess) {
+            // not enough free HBM for the log (other contexts, a huge grid): this launch deposits with atomics instead
+            (void)hipGetLastError();
+            c->d_log_idx.release(); c->d_tmp_idx.release(); c->d_log_val.release(); c->d_tmp_val.release(); c->d_log_fill.release();
+            c->log_alloc_records = 0;
+            use_log = false;
+        }
+    }
+    if (use_log) {
+        // batches use what is allocated; later batches shrink or grow with the measured record rate
+        const size_t cap_records = c->log_alloc_records;
+        const uint32_t cap_chunks = (uint32_t)(cap_records / kLogChunk);
         HIP_TRY(c, c->d_log_meta.ensure(64));
         uint32_t bits2 = 1; while ((1u << (2 * bits2)) < n_tiles) bits2++;
         // grids of <= 1024 tiles (256^3): ONE partition pass straight to tiles.  Records cluster in the few dozen
@@ -634,17 +645,6 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
                 const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 200.0;
                 const double fit = 0.8 * (double)cap_records / rate;
                 if ((double)batch > fit) batch = fit < 4096.0 ? 4096 : (uint64_t)fit;
-            }
-            if (done > 0) {   // re-size with the measured record rate (buffers only ever grow)
-                const size_t want_records = size_log(n_photons - done);
-                if (want_records > cap_records) {
-                    cap_records = want_records; cap_chunks = (uint32_t)(cap_records / kLogChunk);
-                    HIP_TRY(c, ensure_log());
-                    P.log_idx = (uint32_t*)c->d_log_idx.p; P.log_val = c->d_log_val.p; P.log_fill = (uint32_t*)c->d_log_fill.p;
-                    P.log_cap_chunks = cap_chunks;
-                    L.log_idx = P.log_idx; L.log_val = P.log_val; L.log_fill = P.log_fill;
-                    L.tmp_idx = (uint32_t*)c->d_tmp_idx.p; L.tmp_val = c->d_tmp_val.p;
-                }
             }
             P.n_photons = batch; P.photon_offset = photon_offset + done;
             want = (batch + (unsigned long long)cfg.threads - 1) / (unsigned long long)cfg.threads;
@@ -699,7 +699,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
             }
             n_batches++;
             double rate = (double)h[2] / (double)batch;
-            if (overflow) rate *= 1.5;   // part of the batch went through atomics: the true rate is higher
+            if (overflow) rate *= 2.0;   // part of the batch went through atomics: the true rate is higher
             c->rec_per_photon = rate > c->rec_per_photon ? rate : 0.5 * (rate + c->rec_per_photon);
             done += batch;
         }
