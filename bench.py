@@ -48,10 +48,29 @@ def configure(ctx, tally):
     ctx.set_source(0, (0.0, 0.0, 0.0), (0.0, 0.0, 1.0))
 
 
+def effective_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box
+    shows 256 logical CPUs but grants a 16-CPU quota; oversubscribing it makes the oracle slower, not faster)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(np.ceil(int(quota) / int(period)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(np.ceil(q / p_))))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(target_seconds=12.0):
     """CPU oracle (port) on every host core, bounded sample of C2."""
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = effective_cores()
     half = GRID_N * VOXEL / 2
     sc = O.OracleScene([MEDIUM], (GRID_N,) * 3, (-half, -half, 0.0), (VOXEL,) * 3,
                        layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))
