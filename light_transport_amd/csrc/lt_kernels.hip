@@ -12,8 +12,15 @@
 //     photon's uniforms do not depend on which lane / wave / GPU traces it;
 //   * media, layer and BVH/triangle tables are staged once per workgroup into
 //     LDS (all lanes read the same few entries: LDS broadcast);
-//   * energy is deposited with no-return global atomics (f32 / f64 / u64
-//     fixed point); rare per-photon events go to LDS counters.
+//   * deposits: consecutive same-voxel deposits of a lane are merged in
+//     registers; the surviving records go either to the grid with no-return
+//     global atomics (f32 / f64 / u64 fixed point) or -- default for slabs --
+//     into a coalesced deposit log that lt_logtally.hip partitions by grid tile
+//     and reduces in LDS (the memory-side atomic unit, ~16e9 requests/s, was
+//     the limiter; HBM streaming bandwidth is not); rare per-photon events go
+//     to LDS counters;
+//   * f64 arithmetic (the reference's dtype) with lean -ln / sincos / sqrt /
+//     quotient primitives for the hot loop's restricted argument ranges.
 // No MFMA: there is no dense contraction anywhere on this path.
 //
 // Reference citations: S/ = LightTransportSimulator/light_transport/src/.
