@@ -50,3 +50,48 @@ def test_two_ranks_on_device_match_single_run(tmp_path):
     assert bool(r["equal"]) and int(r["total"]) == 1
     assert int(r["steps"]) == int(r["steps_whole"]) and int(r["photons"]) == n
     assert abs(float(r["absorbed"]) - float(r["absorbed_whole"])) < 1e-6
+
+
+def test_lt_reduce_grid_with_a_one_rank_rccl_communicator(ctx):
+    """The C-host form of the reduce: lt_reduce_grid(ctx, ncclComm_t, root) on a communicator created directly from
+    librccl (1 rank: the sum is the identity, which checks symbol loading, datatypes and stream use end to end)."""
+    import ctypes as C
+    import glob
+    import torch
+    import light_transport_amd as lt
+    sys.path.insert(0, ROOT)
+    from tests import scenes as S
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["librccl.so", "librccl.so.1"]
+    rccl = None
+    for c in cands:
+        try:
+            rccl = C.CDLL(c, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("librccl.so not loadable")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        prob = S.two_layer(n=32)
+        for dtype in ("u64fx", "f64", "f32"):
+            prob.apply(ctx, dtype)
+            ctx.launch(20000, seed=3, f32_walk=dtype == "f32"); ctx.sync()
+            before, cb = ctx.read_grid_raw(), ctx.read_counters()
+            for root in (-1, 0):
+                rc = lt.lib().lt_reduce_grid(ctx._h, comm, C.c_int(root))
+                assert rc == 0, lt.lib().lt_last_error(ctx._h)
+                ctx.sync()
+                assert np.array_equal(ctx.read_grid_raw(), before)
+                ca = ctx.read_counters()
+                assert ca["steps"] == cb["steps"] and ca["w_absorbed"] == cb["w_absorbed"]
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
