@@ -54,6 +54,9 @@ struct lt_ctx {
     hipEvent_t evs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries of the last log-mode batch
     bool stages_valid = false;
     uint64_t last_records = 0, last_batches = 0;
+    bool log_stats_pending = false, last_overflow = false;
+    uint64_t pending_batch = 0;
+    uint32_t pending_cap_chunks = 0;
     std::string err;
     hipDeviceProp_t prop;
 
@@ -245,6 +248,25 @@ int upload_tables(lt_ctx* c)
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->tables_dirty = false;
+    return LT_OK;
+}
+
+// Read back the statistics of the last log-mode batch (chunks claimed, records logged) once the stream has
+// drained, and update the deposit-record rate that sizes the next launch's log and batches.
+int collect_log_stats(lt_ctx* c)
+{
+    if (!c->log_stats_pending) return LT_OK;
+    uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_log_meta.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->log_stats_pending = false;
+    c->last_overflow = h[0] > c->pending_cap_chunks;
+    c->last_records = h[2];
+    if (c->pending_batch > 0) {
+        double rate = (double)h[2] / (double)c->pending_batch;
+        if (c->last_overflow) rate *= 2.0;   // part of the batch went through atomics: the true rate is higher
+        c->rec_per_photon = rate > c->rec_per_photon ? rate : 0.5 * (rate + c->rec_per_photon);
+    }
     return LT_OK;
 }
 
@@ -553,6 +575,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     // auto: slab walks are paced by the atomic unit -> log; mesh walks are paced by BVH arithmetic, which hides the
     // atomics, so the extra log passes would only add time (C4: 101 ms atomic vs 114 ms log)
     const int mode = c->tally_mode == 2 ? (c->have_mesh ? 0 : 1) : c->tally_mode;
+    { int rc3 = collect_log_stats(c); if (rc3) return rc3; }   // stats of the previous launch size this one
     bool use_log = mode == 1 && !v.table && c->max_vertices == 0 && n_tiles <= 16384 && !std::getenv("LT_DIAG_NO_TALLY");
     if (use_log) {
         const size_t rec_bytes = 4 + c->grid_elem();
@@ -632,12 +655,14 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         L.grid = c->d_grid.p; L.n_vox = c->n_vox(); L.tally = c->tally;
         L.nx = (uint32_t)c->nx; L.ny = (uint32_t)c->ny; L.nz = (uint32_t)c->nz; L.ntx = ntx; L.nty = nty;
 
+        L.chunks_used = meta; L.cap_chunks = cap_chunks; L.work = meta + 5;
+        // Everything below is enqueued without a host read-back: item counts stay in device memory and the
+        // partition / reduce kernels are persistent work loops.  Statistics of the LAST batch (records, overflow)
+        // are collected lazily (collect_log_stats) and steer the batch size of the next launch.
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         uint64_t done = 0;
-        const bool diag = std::getenv("LT_LOG_TIMING") != nullptr;   // per-stage device times (adds syncs)
-        hipEvent_t te[8];
-        double stage[6] = {0, 0, 0, 0, 0, 0};
-        if (diag) for (auto& e : te) HIP_TRY(c, hipEventCreate(&e));
+        const bool diag = std::getenv("LT_LOG_TIMING") != nullptr;   // prints per-stage device times (syncs per batch)
+        double stage[4] = {0, 0, 0, 0};
         int n_batches = 0;
         while (done < n_photons) {
             uint64_t batch = n_photons - done;
@@ -653,63 +678,39 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
             HIP_TRY(c, hipMemsetAsync(c->d_head.p, 0, sizeof(unsigned long long), c->stream));
             HIP_TRY(c, hipMemsetAsync(meta, 0, 32, c->stream));
             HIP_TRY(c, hipMemsetAsync(c->d_hist.p, 0, (size_t)n_tiles * 4, c->stream));
-            if (diag) HIP_TRY(c, hipEventRecord(te[0], c->stream));
             HIP_TRY(c, hipEventRecord(c->evs[0], c->stream));
             HIP_TRY(c, launch_walk(P, v, cfg, c->stream));
             HIP_TRY(c, hipEventRecord(c->evs[1], c->stream));
-            if (diag) HIP_TRY(c, hipEventRecord(te[7], c->stream));
-            uint32_t h[5] = {0, 0, 0, 0, 0};
-            HIP_TRY(c, hipMemcpyAsync(h, meta, 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            const bool overflow = h[0] > cap_chunks;
-            L.n_chunks = h[0] < cap_chunks ? h[0] : cap_chunks;
-            if (diag) HIP_TRY(c, hipEventRecord(te[1], c->stream));
-            if (diag) HIP_TRY(c, hipEventRecord(te[2], c->stream));   // (tile histogram now comes from the walk)
             HIP_TRY(c, launch_log_scan(L, c->stream));
             HIP_TRY(c, hipEventRecord(c->evs[2], c->stream));
-            if (diag) HIP_TRY(c, hipEventRecord(te[3], c->stream));
-            HIP_TRY(c, hipMemcpyAsync(h + 2, meta + 2, 12, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (diag) HIP_TRY(c, hipEventRecord(te[3], c->stream));
             HIP_TRY(c, launch_log_part1(L, c->stream));
-            HIP_TRY(c, hipEventRecord(c->evs[3], c->stream));
-            if (diag) HIP_TRY(c, hipEventRecord(te[4], c->stream));
             LogReduceParams Lr = L;
             if (bits2 == 0) { Lr.log_idx = L.tmp_idx; Lr.log_val = L.tmp_val; }   // single pass: tiles are final in tmp
-            else HIP_TRY(c, launch_log_part2(L, h[3], c->stream));
-            if (diag) HIP_TRY(c, hipEventRecord(te[5], c->stream));
+            else HIP_TRY(c, launch_log_part2(L, c->stream));
             HIP_TRY(c, hipEventRecord(c->evs[4], c->stream));
-            HIP_TRY(c, launch_log_reduce(Lr, h[4], c->stream));
+            HIP_TRY(c, launch_log_reduce(Lr, c->stream));
             HIP_TRY(c, hipEventRecord(c->evs[5], c->stream));
-            c->last_records = h[2];
+            c->log_stats_pending = true; c->pending_batch = batch; c->pending_cap_chunks = cap_chunks;
             if (diag) {
-                HIP_TRY(c, hipEventRecord(te[6], c->stream));
-                HIP_TRY(c, hipEventSynchronize(te[6]));
-                // te[1] and te[3] were re-recorded after the host syncs, so hist and part1 exclude the sync gaps
+                int rc2 = collect_log_stats(c);
+                if (rc2) return rc2;
                 float f;
-                (void)hipEventElapsedTime(&f, te[0], te[7]); stage[0] += f;
-                (void)hipEventElapsedTime(&f, te[1], te[2]); stage[1] += f;
-                (void)hipEventElapsedTime(&f, te[2], te[3]); stage[2] += f;
-                (void)hipEventElapsedTime(&f, te[3], te[4]); stage[3] += f;
-                (void)hipEventElapsedTime(&f, te[4], te[5]); stage[4] += f;
-                (void)hipEventElapsedTime(&f, te[5], te[6]); stage[5] += f;
-                std::fprintf(stderr, "[lt log] batch %d: %llu photons, %u chunks, %u records (%.1f / photon), %u pass-2 items%s\n",
-                             n_batches, (unsigned long long)batch, L.n_chunks, h[2], (double)h[2] / (double)batch, h[3],
-                             overflow ? ", LOG OVERFLOW -> atomics" : "");
+                (void)hipEventElapsedTime(&f, c->evs[0], c->evs[1]); stage[0] += f;
+                (void)hipEventElapsedTime(&f, c->evs[1], c->evs[2]); stage[1] += f;
+                (void)hipEventElapsedTime(&f, c->evs[2], c->evs[4]); stage[2] += f;
+                (void)hipEventElapsedTime(&f, c->evs[4], c->evs[5]); stage[3] += f;
+                std::fprintf(stderr, "[lt log] batch %d: %llu photons, %llu records (%.1f / photon)%s\n", n_batches,
+                             (unsigned long long)batch, (unsigned long long)c->last_records,
+                             (double)c->last_records / (double)batch, c->last_overflow ? ", LOG OVERFLOW -> atomics" : "");
             }
             n_batches++;
-            double rate = (double)h[2] / (double)batch;
-            if (overflow) rate *= 2.0;   // part of the batch went through atomics: the true rate is higher
-            c->rec_per_photon = rate > c->rec_per_photon ? rate : 0.5 * (rate + c->rec_per_photon);
             done += batch;
         }
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         c->stages_valid = true; c->last_batches = (uint64_t)n_batches;
-        if (diag) {
-            std::fprintf(stderr, "[lt log] stages ms: walk %.2f hist %.2f scan %.2f part1 %.2f part2 %.2f reduce %.2f\n",
-                         stage[0], stage[1], stage[2], stage[3], stage[4], stage[5]);
-            for (auto& e : te) (void)hipEventDestroy(e);
-        }
+        if (diag)
+            std::fprintf(stderr, "[lt log] stages ms: walk %.2f scan %.2f partition %.2f reduce %.2f\n", stage[0], stage[1],
+                         stage[2], stage[3]);
         c->timed = true;
         return LT_OK;
     }
@@ -758,7 +759,7 @@ int lt_sync(lt_ctx* c)
     CHECK_CTX(c);
     BIND(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return LT_OK;
+    return collect_log_stats(c);
 }
 
 int lt_last_kernel_ms(lt_ctx* c, double* ms)
@@ -781,6 +782,7 @@ int lt_last_log_stages(lt_ctx* c, double ms_out[4], uint64_t* records, uint64_t*
     if (!c->stages_valid) return c->fail(LT_E_STATE, "lt_last_log_stages: the last launch did not use the log tally");
     BIND(c);
     HIP_TRY(c, hipEventSynchronize(c->evs[5]));
+    { int rc3 = collect_log_stats(c); if (rc3) return rc3; }
     float f;
     HIP_TRY(c, hipEventElapsedTime(&f, c->evs[0], c->evs[1])); ms_out[0] = f;   // walk
     HIP_TRY(c, hipEventElapsedTime(&f, c->evs[1], c->evs[2])); ms_out[1] = f;   // counts readback + scan

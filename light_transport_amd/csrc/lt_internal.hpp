@@ -139,6 +139,9 @@ struct LogReduceParams {
     uint32_t* items2;                          // [nb1 + 1] prefix of pass-2 work items per level-1 bin
     uint32_t* items_r;                         // [n_tiles + 1] prefix of reduce work items per tile
     uint32_t* totals;                          // [3]: total records, pass-2 items, reduce items
+    const uint32_t* chunks_used;               // [1]: chunks the walk claimed (may exceed cap_chunks on overflow)
+    uint32_t cap_chunks;
+    uint32_t* work;                            // [3]: work-item counters of part1, part2, reduce (zeroed per batch)
     uint32_t n_tiles, bits2;                   // level-2 digit width; level-1 bins = ceil(n_tiles >> bits2)
     void* grid; size_t n_vox; int tally;
     uint32_t nx, ny, nz, ntx, nty;             // grid shape and tile counts along x, y (tiled record index)
@@ -146,8 +149,8 @@ struct LogReduceParams {
 hipError_t launch_log_hist(const LogReduceParams& L, hipStream_t s);
 hipError_t launch_log_scan(const LogReduceParams& L, hipStream_t s);
 hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s);
-hipError_t launch_log_part2(const LogReduceParams& L, uint32_t n_items, hipStream_t s);
-hipError_t launch_log_reduce(const LogReduceParams& L, uint32_t n_items, hipStream_t s);
+hipError_t launch_log_part2(const LogReduceParams& L, hipStream_t s);
+hipError_t launch_log_reduce(const LogReduceParams& L, hipStream_t s);
 
 hipError_t launch_intersect_rays(const void* tris, const void* nodes, int n_tris, int n_nodes,
                                  const double* o, const double* d, const double* tmax, size_t n,

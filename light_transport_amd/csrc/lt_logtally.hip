@@ -123,16 +123,23 @@ constexpr int kPerThread = kLogChunk / kPartThreads;  // 16
 constexpr int kMaxBins = 1024;
 
 template <typename TV, int PASS>
-__global__ void __launch_bounds__(kPartThreads) k_log_part(LogReduceParams L, uint32_t n_items)
+__global__ void __launch_bounds__(kPartThreads) k_log_part(LogReduceParams L)
 {
     __shared__ uint32_t s_hist[kMaxBins], s_off[kMaxBins + 1], s_gbase[kMaxBins];
-    __shared__ uint32_t s_range[3];
+    __shared__ uint32_t s_range[3], s_next;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // digit-sorted copy of the item (96 KiB at 12 B)
     TV* s_val = reinterpret_cast<TV*>(s_dyn);
     uint32_t* s_key = reinterpret_cast<uint32_t*>(s_dyn + (size_t)kLogChunk * sizeof(TV));
 
-    const uint32_t item = blockIdx.x;
-    if (item >= n_items) return;
+    // Persistent workgroups pull work items from a device counter; the item count lives in device memory too
+    // (chunks the walk claimed / items the scan derived), so the host never has to read anything back.
+    uint32_t n_items = PASS == 1 ? L.chunks_used[0] : L.totals[1];
+    if (PASS == 1 && n_items > L.cap_chunks) n_items = L.cap_chunks;
+  for (;;) {
+    if (threadIdx.x == 0) s_next = atomicAdd(&L.work[PASS - 1], 1u);
+    __syncthreads();
+    const uint32_t item = s_next;
+    if (item >= n_items) break;
     const uint32_t nb1 = (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2;
     const uint32_t mask2 = (1u << L.bits2) - 1;
     const uint32_t* in_idx; const TV* in_val; uint32_t* out_idx; TV* out_val; uint32_t* cursor; uint32_t nb;
@@ -207,20 +214,26 @@ __global__ void __launch_bounds__(kPartThreads) k_log_part(LogReduceParams L, ui
         const uint32_t dst = s_gbase[d] + (p - s_off[d]);
         out_idx[dst] = kk; out_val[dst] = s_val[p];
     }
+    __syncthreads();   // LDS is reused by the next item
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kReduceThreads = 512;
 
 template <typename TV>
-__global__ void __launch_bounds__(kReduceThreads) k_log_reduce(LogReduceParams L, uint32_t n_items)
+__global__ void __launch_bounds__(kReduceThreads) k_log_reduce(LogReduceParams L)
 {
     typedef typename AccT<TV>::type AT;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     AT* s_tile = reinterpret_cast<AT*>(s_raw);
-    __shared__ uint32_t s_item[3];
-    const uint32_t item = blockIdx.x;
-    if (item >= n_items) return;
+    __shared__ uint32_t s_item[3], s_next;
+    const uint32_t n_items = L.totals[2];
+  for (;;) {
+    if (threadIdx.x == 0) s_next = atomicAdd(&L.work[2], 1u);
+    __syncthreads();
+    const uint32_t item = s_next;
+    if (item >= n_items) break;
     if (threadIdx.x == 0) {   // tile of this work item: items_r is a prefix over tiles
         uint32_t a = 0, b = L.n_tiles;
         while (b - a > 1) { uint32_t m = (a + b) >> 1; if (L.items_r[m] <= item) a = m; else b = m; }
@@ -255,6 +268,8 @@ __global__ void __launch_bounds__(kReduceThreads) k_log_reduce(LogReduceParams L
             else *dst += a;   // exclusive owner of this tile: plain read-add-write
         }
     }
+    __syncthreads();   // the LDS tile is re-zeroed for the next item
+  }
 }
 
 }  // namespace
@@ -275,7 +290,17 @@ hipError_t launch_log_scan(const LogReduceParams& L, hipStream_t s)
     return hipGetLastError();
 }
 
-template <typename TV, int PASS> static hipError_t launch_part_t(const LogReduceParams& L, uint32_t n_items, hipStream_t s)
+// persistent grids: as many workgroups as are resident at once (occupancy query x CUs)
+static unsigned persistent_blocks(const void* fn, int threads, size_t lds)
+{
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    return (unsigned)(per_cu * cus);
+}
+
+template <typename TV, int PASS> static hipError_t launch_part_t(const LogReduceParams& L, hipStream_t s)
 {
     const size_t lds = (size_t)kLogChunk * (sizeof(TV) + sizeof(uint32_t));
     const void* fn = reinterpret_cast<const void*>(&k_log_part<TV, PASS>);
@@ -283,20 +308,21 @@ template <typename TV, int PASS> static hipError_t launch_part_t(const LogReduce
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_log_part<TV, PASS>), dim3(n_items), dim3(kPartThreads), lds, s, L, n_items);
+    static unsigned blocks = 0;   // per instantiation
+    if (!blocks) blocks = persistent_blocks(fn, kPartThreads, lds);
+    hipLaunchKernelGGL((k_log_part<TV, PASS>), dim3(blocks), dim3(kPartThreads), lds, s, L);
     return hipGetLastError();
 }
-template <int PASS> static hipError_t launch_part(const LogReduceParams& L, uint32_t n_items, hipStream_t s)
+template <int PASS> static hipError_t launch_part(const LogReduceParams& L, hipStream_t s)
 {
-    if (n_items == 0) return hipSuccess;
-    if (L.tally == LT_TALLY_F32) return launch_part_t<float, PASS>(L, n_items, s);
-    if (L.tally == LT_TALLY_F64) return launch_part_t<double, PASS>(L, n_items, s);
-    return launch_part_t<unsigned long long, PASS>(L, n_items, s);
+    if (L.tally == LT_TALLY_F32) return launch_part_t<float, PASS>(L, s);
+    if (L.tally == LT_TALLY_F64) return launch_part_t<double, PASS>(L, s);
+    return launch_part_t<unsigned long long, PASS>(L, s);
 }
-hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s) { return launch_part<1>(L, L.n_chunks, s); }
-hipError_t launch_log_part2(const LogReduceParams& L, uint32_t n_items, hipStream_t s) { return launch_part<2>(L, n_items, s); }
+hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s) { return launch_part<1>(L, s); }
+hipError_t launch_log_part2(const LogReduceParams& L, hipStream_t s) { return launch_part<2>(L, s); }
 
-template <typename TV> static hipError_t launch_reduce_t(const LogReduceParams& L, uint32_t n_items, hipStream_t s)
+template <typename TV> static hipError_t launch_reduce_t(const LogReduceParams& L, hipStream_t s)
 {
     const size_t lds = (size_t)kTileSize * sizeof(typename AccT<TV>::type);
     const void* fn = reinterpret_cast<const void*>(&k_log_reduce<TV>);
@@ -304,15 +330,16 @@ template <typename TV> static hipError_t launch_reduce_t(const LogReduceParams& 
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_log_reduce<TV>, dim3(n_items), dim3(kReduceThreads), lds, s, L, n_items);
+    static unsigned blocks = 0;
+    if (!blocks) blocks = persistent_blocks(fn, kReduceThreads, lds);
+    hipLaunchKernelGGL(k_log_reduce<TV>, dim3(blocks), dim3(kReduceThreads), lds, s, L);
     return hipGetLastError();
 }
-hipError_t launch_log_reduce(const LogReduceParams& L, uint32_t n_items, hipStream_t s)
+hipError_t launch_log_reduce(const LogReduceParams& L, hipStream_t s)
 {
-    if (n_items == 0) return hipSuccess;
-    if (L.tally == LT_TALLY_F32) return launch_reduce_t<float>(L, n_items, s);
-    if (L.tally == LT_TALLY_F64) return launch_reduce_t<double>(L, n_items, s);
-    return launch_reduce_t<unsigned long long>(L, n_items, s);
+    if (L.tally == LT_TALLY_F32) return launch_reduce_t<float>(L, s);
+    if (L.tally == LT_TALLY_F64) return launch_reduce_t<double>(L, s);
+    return launch_reduce_t<unsigned long long>(L, s);
 }
 
 }  // namespace ltk
