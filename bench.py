@@ -197,7 +197,8 @@ def main():
                                    "n=1), %d^3 voxel grid (%.1f mm), pencil beam" % (per_gpu, GRID_N, VOXEL),
                        "tally": args.tally, "tally_mode": args.tally_mode, "rng": "rocRAND XORWOW, re-seeded per photon",
                        "parallelism": "photon-id sharding x%d, RCCL reduce of the grid to rank 0 per step" % world
-                       if world > 1 else "single GPU", "device": info["name"], "cus": info["cus"]},
+                       if world > 1 else "single GPU", "device": info["name"], "cus": info["cus"],
+                       "clock_mhz": info["clock_mhz"], "hbm_gib": round(info["hbm_bytes"] / 2 ** 30, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "walk_kernel + k_log_scan/part/reduce (one job)" if args.tally_mode == "log"
