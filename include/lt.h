@@ -263,6 +263,18 @@ int lt_render_surface(lt_ctx* ctx, int width, int height, int samples, int max_d
                       const double camera[3], double f_distance, const double* xs,
                       const double* ys, double* rand_0, const double* rand_1,
                       const int32_t* light_choice, double* image);
+/* role of render_scene + trace_path of path_tracing_old.py:17-171, the recursive
+ * integrator examples/LTS.ipynb calls: a diffuse hit recurses on the shared ray
+ * and carries on from where the callee left it (:68-80), emission counts at
+ * bounce 0 only (:45), roulette starts after bounce 3 (:127).  Same tables as
+ * lt_render_surface, except that one path casts up to 2^max_depth - 1 shadow
+ * rays: light_choice is [H][W][S][choices_per_sample] and the k-th shadow ray of
+ * a sample (depth-first order) uses entry k mod choices_per_sample.
+ * max_depth <= 24.  image [H][W][3] is OVERWRITTEN with clip(mean colour) (:167). */
+int lt_render_surface_old(lt_ctx* ctx, int width, int height, int samples, int max_depth,
+                          const double camera[3], double f_distance, const double* xs,
+                          const double* ys, double* rand_0, const double* rand_1,
+                          const int32_t* light_choice, int choices_per_sample, double* image);
 
 /* ---- light sub-path vertices ("photon map" output) ----- */
 /* Role of the Vertex record and of generate_light_subpaths / random_walk

@@ -28,7 +28,7 @@ SYMBOLS = [
     "lt_grid_device_ptr", "lt_counters_device_ptr", "lt_stream", "lt_reduce_grid", "lt_intersect_rays",
     "lt_triangle_intersect", "lt_intersect_bounds", "lt_eval", "lt_rng_raw", "lt_device_info",
     "lt_set_surface_materials", "lt_set_lights", "lt_render_surface", "lt_set_vertex_capture", "lt_read_vertices",
-    "lt_set_tally_mode", "lt_last_log_stages", "lt_reserve_log",
+    "lt_set_tally_mode", "lt_last_log_stages", "lt_reserve_log", "lt_render_surface_old",
 ]
 
 # lt_vertex as a NumPy record (72 bytes, same layout as the C struct)
@@ -354,19 +354,26 @@ class Context:
     def set_lights(self, lights):
         self._ck(lib().lt_set_lights(self._h, lights, C.c_int(len(lights))), "lt_set_lights")
 
-    def render_surface(self, camera, f_distance, xs, ys, rand_0, rand_1, light_choice, image):
-        """rand_0 [H,W,S,D] and image [H,W,3] are updated in place (C-contiguous float64)."""
+    def render_surface(self, camera, f_distance, xs, ys, rand_0, rand_1, light_choice, image, old=False):
+        """rand_0 [H,W,S,D] and image [H,W,3] are updated in place (C-contiguous float64).  old=True: the recursive
+        path_tracing_old integrator; light_choice is then [H,W,S,choices_per_sample] and image is overwritten."""
         H, W, S, D = rand_0.shape
         for a in (rand_0, rand_1, image):
             if a.dtype != np.float64 or not a.flags["C_CONTIGUOUS"]:
                 raise LtError("render_surface: tables and image must be C-contiguous float64")
         lc = np.ascontiguousarray(light_choice, dtype=np.int32)
-        if rand_1.shape != rand_0.shape or lc.shape != rand_0.shape or image.shape != (H, W, 3):
+        lc_ok = (lc.ndim == 4 and lc.shape[:3] == (H, W, S) and lc.shape[3] > 0) if old else lc.shape == rand_0.shape
+        if rand_1.shape != rand_0.shape or not lc_ok or image.shape != (H, W, 3):
             raise LtError("render_surface: inconsistent table / image shapes")
         cam = (C.c_double * 3)(*[float(x) for x in np.asarray(camera).ravel()[:3]])
         xs, ys = _f64(xs), _f64(ys)
         if xs.size != W or ys.size != H:
             raise LtError("render_surface: xs / ys must have W / H entries")
+        if old:
+            self._ck(lib().lt_render_surface_old(self._h, C.c_int(W), C.c_int(H), C.c_int(S), C.c_int(D), cam,
+                                                 C.c_double(f_distance), _dp(xs), _dp(ys), _dp(rand_0), _dp(rand_1),
+                                                 _ip(lc), C.c_int(lc.shape[3]), _dp(image)), "lt_render_surface_old")
+            return image
         self._ck(lib().lt_render_surface(self._h, C.c_int(W), C.c_int(H), C.c_int(S), C.c_int(D), cam,
                                          C.c_double(f_distance), _dp(xs), _dp(ys), _dp(rand_0), _dp(rand_1), _ip(lc),
                                          _dp(image)), "lt_render_surface")

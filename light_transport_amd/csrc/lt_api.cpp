@@ -1053,18 +1053,22 @@ int lt_set_lights(lt_ctx* c, const lt_point_light* lights, int n)
     return LT_OK;
 }
 
-int lt_render_surface(lt_ctx* c, int width, int height, int samples, int max_depth, const double camera[3],
-                      double f_distance, const double* xs, const double* ys, double* rand_0, const double* rand_1,
-                      const int32_t* light_choice, double* image)
+static int render_impl(lt_ctx* c, int variant, int choices, int width, int height, int samples, int max_depth,
+                       const double camera[3], double f_distance, const double* xs, const double* ys, double* rand_0,
+                       const double* rand_1, const int32_t* light_choice, double* image)
 {
     CHECK_CTX(c);
     if (!c->have_mesh || c->surf_mats.empty() || c->lights.empty())
         return c->fail(LT_E_STATE, "lt_render_surface: lt_set_mesh, lt_set_surface_materials and lt_set_lights first");
     if (width <= 0 || height <= 0 || samples <= 0 || max_depth <= 0 || !camera || !xs || !ys || !rand_0 || !rand_1 ||
-        !light_choice || !image)
+        !light_choice || !image || choices <= 0)
         return c->fail(LT_E_INVALID, "lt_render_surface: bad argument");
+    if (variant == 1 && max_depth > kRenderOldMaxDepth)
+        return c->fail(LT_E_INVALID, "lt_render_surface_old: max_depth %d > %d (the recursion is unrolled on a fixed stack)",
+                       max_depth, kRenderOldMaxDepth);
     const size_t n_tab = (size_t)width * height * samples * max_depth;
-    for (size_t k = 0; k < n_tab; k++)
+    const size_t n_lc = (size_t)width * height * samples * choices;
+    for (size_t k = 0; k < n_lc; k++)
         if (light_choice[k] < 0 || light_choice[k] >= (int)c->lights.size())
             return c->fail(LT_E_INVALID, "lt_render_surface: light_choice[%zu] out of range", k);
     BIND(c);
@@ -1074,13 +1078,13 @@ int lt_render_surface(lt_ctx* c, int width, int height, int samples, int max_dep
     const size_t n_img = (size_t)width * height * 3;
     HIP_TRY(c, c->d_mats.ensure(c->surf_mats.size() * sizeof(lt_surface_material)));
     HIP_TRY(c, c->d_lights.ensure(c->lights.size() * sizeof(lt_point_light)));
-    HIP_TRY(c, c->d_r0.ensure(n_tab * 8)); HIP_TRY(c, c->d_r1.ensure(n_tab * 8)); HIP_TRY(c, c->d_lc.ensure(n_tab * 4));
+    HIP_TRY(c, c->d_r0.ensure(n_tab * 8)); HIP_TRY(c, c->d_r1.ensure(n_tab * 8)); HIP_TRY(c, c->d_lc.ensure(n_lc * 4));
     HIP_TRY(c, c->d_img.ensure(n_img * 8)); HIP_TRY(c, c->d_xy.ensure((size_t)(width + height) * 8));
     HIP_TRY(c, hipMemcpyAsync(c->d_mats.p, c->surf_mats.data(), c->surf_mats.size() * sizeof(lt_surface_material), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_lights.p, c->lights.data(), c->lights.size() * sizeof(lt_point_light), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_r0.p, rand_0, n_tab * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_r1.p, rand_1, n_tab * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_lc.p, light_choice, n_tab * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_lc.p, light_choice, n_lc * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_img.p, image, n_img * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_xy.p, xs, (size_t)width * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync((double*)c->d_xy.p + width, ys, (size_t)height * 8, hipMemcpyHostToDevice, c->stream));
@@ -1095,6 +1099,7 @@ int lt_render_surface(lt_ctx* c, int width, int height, int samples, int max_dep
     P.xs = (const double*)c->d_xy.p; P.ys = (const double*)c->d_xy.p + width;
     P.rand_0 = (double*)c->d_r0.p; P.rand_1 = (const double*)c->d_r1.p; P.light_choice = (const int32_t*)c->d_lc.p;
     P.image = (double*)c->d_img.p;
+    P.variant = variant; P.choices = choices;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, launch_render_surface(P, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -1103,6 +1108,22 @@ int lt_render_surface(lt_ctx* c, int width, int height, int samples, int max_dep
     HIP_TRY(c, hipMemcpyAsync(rand_0, c->d_r0.p, n_tab * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return LT_OK;
+}
+
+int lt_render_surface(lt_ctx* c, int width, int height, int samples, int max_depth, const double camera[3],
+                      double f_distance, const double* xs, const double* ys, double* rand_0, const double* rand_1,
+                      const int32_t* light_choice, double* image)
+{
+    return render_impl(c, 0, max_depth, width, height, samples, max_depth, camera, f_distance, xs, ys, rand_0, rand_1,
+                       light_choice, image);
+}
+
+int lt_render_surface_old(lt_ctx* c, int width, int height, int samples, int max_depth, const double camera[3],
+                          double f_distance, const double* xs, const double* ys, double* rand_0, const double* rand_1,
+                          const int32_t* light_choice, int choices_per_sample, double* image)
+{
+    return render_impl(c, 1, choices_per_sample, width, height, samples, max_depth, camera, f_distance, xs, ys, rand_0,
+                       rand_1, light_choice, image);
 }
 
 int lt_device_info(lt_ctx* c, char* name, size_t name_len, int* n_cus, int* clock_mhz, size_t* hbm_bytes)

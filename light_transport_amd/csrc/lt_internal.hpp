@@ -123,7 +123,10 @@ struct RenderParams {
     const double* rand_1;
     const int32_t* light_choice;
     double* image;
+    int variant;   // 0 = path_tracing_fix1.trace_path, 1 = path_tracing_old.trace_path
+    int choices;   // variant 1: light_choice entries per sample
 };
+constexpr int kRenderOldMaxDepth = 24;   // frames of the unrolled recursion (variant 1)
 hipError_t launch_build_clearance(const void* tris_f64, int n_tris, float* clear, int nx, int ny, int nz,
                                   const double org[3], const double cell[3], hipStream_t s);
 hipError_t launch_render_surface(const RenderParams& P, hipStream_t s);

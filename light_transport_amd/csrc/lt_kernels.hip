@@ -1093,6 +1093,60 @@ LT_DEV void mark_unused(double* rand_0, size_t base, int from, int D)  // :36-38
     for (int b = from; b < D; b++) rand_0[base + b] = __builtin_huge_val();
 }
 
+// cast_one_shadow_ray (S/light_samples.py:36-61): radiance * brdf * geometry term * area of light sample `choice`
+// as seen from X (offset along n); false when the sample is occluded.
+__device__ __forceinline__ bool shadow_direct(const RenderParams& P, const TriD<double>* tris, const NodeD<double>* nodes,
+                                              const double X[3], const double n[3], const lt_surface_material& M,
+                                              int choice, double out[3])
+{
+    const double eps = 1e-6, inv_pi = 0.3183098861837907, inf = __builtin_huge_val();
+    const double so[3] = {X[0] + eps * n[0], X[1] + eps * n[1], X[2] + eps * n[2]};
+    const lt_point_light lt = P.lights[choice];
+    double v[3] = {lt.source[0] - so[0], lt.source[1] - so[1], lt.source[2] - so[2]};
+    const double mag = ::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const double sd[3] = {v[0] / mag, v[1] / mag, v[2] / mag};
+    int sp; double st;
+    nearest_bvh(tris, nodes, P.n_nodes, so, sd, inf, sp, st);
+    if (!(st >= mag - eps)) return false;
+    const double cos_t = dot3(n, sd);
+    const double nsd[3] = {-sd[0], -sd[1], -sd[2]};
+    const double cos_p = dot3(lt.normal, nsd);
+    const double geom = ::fabs(cos_t * cos_p) / (mag * mag);
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[k] = (lt.radiance[k] * (M.diffuse[k] * inv_pi)) * geom * lt.total_area;
+    return true;
+}
+
+// mirror (:82-85) and glass (:86-119, kept as written, quirk B5) branches of trace_path: new ray in o, d
+__device__ __forceinline__ void specular_bounce(const lt_surface_material& M, const double X[3], const double n[3],
+                                                bool inside, double r0, double o[3], double d[3])
+{
+    const double eps = 1e-6;
+    if (!M.is_mirror) {
+        const double n1 = inside ? M.ior : 1.0, n2 = inside ? 1.0 : M.ior;
+        const double R0 = ((n1 - n2) / (n1 + n2)) * ((n1 - n2) / (n1 + n2));
+        const double theta = dot3(d, n);
+        const double refl_prob = R0 + (1 - R0) * ::pow(1 - ::cos(theta), 5.0);
+        double Nr = M.ior;
+        if (theta > 0) Nr = 1 / Nr;
+        Nr = 1 / Nr;
+        const double cos_theta = -theta;
+        const double rad = 1 - (Nr * Nr) * (1 - cos_theta * cos_theta);
+        if (rad > 0 && r0 > refl_prob) {
+            const double kk = Nr * cos_theta - ::sqrt(rad);
+            double tr[3] = {d[0] * Nr + n[0] * kk, d[1] * Nr + n[1] * kk, d[2] * Nr + n[2] * kk};
+            normalize3(tr);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { o[k] = X[k] - eps * n[k]; d[k] = tr[k]; }
+            return;
+        }
+    }
+    double r[3]; reflect(d, n, r);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { o[k] = X[k] + eps * n[k]; d[k] = r[k]; }
+}
+
+
 __global__ void __launch_bounds__(64) k_render_surface(const RenderParams P)
 {
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1124,20 +1178,10 @@ __global__ void __launch_bounds__(64) k_render_surface(const RenderParams P)
             if (dot3(n, d) > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; inside = true; }   // :48-51
             if (M.is_diffuse) {
                 // direct light: cast_one_shadow_ray, S/light_samples.py:36-61
-                const double so[3] = {X[0] + eps * n[0], X[1] + eps * n[1], X[2] + eps * n[2]};
-                const lt_point_light lt = P.lights[P.light_choice[base + bounce]];
-                double v[3] = {lt.source[0] - so[0], lt.source[1] - so[1], lt.source[2] - so[2]};
-                const double mag = ::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-                const double sd[3] = {v[0] / mag, v[1] / mag, v[2] / mag};
-                int sp; double st;
-                nearest_bvh(tris, nodes, P.n_nodes, so, sd, inf, sp, st);
-                if (st >= mag - eps) {
-                    const double cos_t = dot3(n, sd);
-                    const double nsd[3] = {-sd[0], -sd[1], -sd[2]};
-                    const double cos_p = dot3(lt.normal, nsd);
-                    const double geom = ::fabs(cos_t * cos_p) / (mag * mag);
+                double direct[3];
+                if (shadow_direct(P, tris, nodes, X, n, M, P.light_choice[base + bounce], direct)) {
 #pragma unroll
-                    for (int k = 0; k < 3; k++) L[k] += thr[k] * ((lt.radiance[k] * (M.diffuse[k] * inv_pi)) * geom * lt.total_area);
+                    for (int k = 0; k < 3; k++) L[k] += thr[k] * direct[k];
                 }
                 // indirect: cosine lobe, :63-80
                 double o4[4];
@@ -1150,31 +1194,8 @@ __global__ void __launch_bounds__(64) k_render_surface(const RenderParams P)
                     o[k] = X[k] + eps * o4[k];
                     d[k] = o4[k];
                 }
-            } else if (M.is_mirror) {                                   // :82-85
-                double r[3]; reflect(d, n, r);
-#pragma unroll
-                for (int k = 0; k < 3; k++) { o[k] = X[k] + eps * n[k]; d[k] = r[k]; }
-            } else if (M.transmission > 0.0) {                          // :86-119 (kept as written, quirk B5)
-                const double n1 = inside ? M.ior : 1.0, n2 = inside ? 1.0 : M.ior;
-                const double R0 = ((n1 - n2) / (n1 + n2)) * ((n1 - n2) / (n1 + n2));
-                const double theta = dot3(d, n);
-                const double refl_prob = R0 + (1 - R0) * ::pow(1 - ::cos(theta), 5.0);
-                double Nr = M.ior;
-                if (theta > 0) Nr = 1 / Nr;
-                Nr = 1 / Nr;
-                const double cos_theta = -theta;
-                const double rad = 1 - (Nr * Nr) * (1 - cos_theta * cos_theta);
-                if (rad > 0 && r0 > refl_prob) {
-                    const double kk = Nr * cos_theta - ::sqrt(rad);
-                    double tr[3] = {d[0] * Nr + n[0] * kk, d[1] * Nr + n[1] * kk, d[2] * Nr + n[2] * kk};
-                    normalize3(tr);
-#pragma unroll
-                    for (int k = 0; k < 3; k++) { o[k] = X[k] - eps * n[k]; d[k] = tr[k]; }
-                } else {
-                    double r[3]; reflect(d, n, r);
-#pragma unroll
-                    for (int k = 0; k < 3; k++) { o[k] = X[k] + eps * n[k]; d[k] = r[k]; }
-                }
+            } else if (M.is_mirror || M.transmission > 0.0) {           // :82-119
+                specular_bounce(M, X, n, inside, r0, o, d);
             } else break;                                               // :121-123
             if (bounce > 5) {                                           // russian roulette, :126-132
                 const double rr = ::fmax(0.05, 1 - thr[1]);
@@ -1193,11 +1214,114 @@ __global__ void __launch_bounds__(64) k_render_surface(const RenderParams P)
     }
 }
 
+// path_tracing_old.py:17-171 -- the recursive ancestor of trace_path that examples/LTS.ipynb still calls.  A diffuse hit
+// calls trace_path(ray, bounce + 1) on the SHARED ray and, once that returns, carries on from wherever the callee left
+// the ray (:68-80); emission counts at bounce 0 only (:45), the direct term is not throughput-weighted (:80), roulette
+// starts after bounce 3 (:127) and the pixel is overwritten with clip(mean) (:167).  The recursion is unrolled into an
+// explicit per-lane stack of (throughput, light, direct, r0, bounce) frames, visited in the reference's depth-first
+// order so that the +inf markers written into rand_0 are read back exactly where the reference reads them.
+struct OldFrame { double thr[3], L[3], direct[3], r0; int bounce; };
+
+__global__ void __launch_bounds__(64) k_render_surface_old(const RenderParams P)
+{
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= P.W * P.H) return;
+    const int i = pix / P.W, j = pix % P.W;
+    const TriD<double>* tris = reinterpret_cast<const TriD<double>*>(P.tris);
+    const NodeD<double>* nodes = reinterpret_cast<const NodeD<double>*>(P.nodes);
+    const double eps = 1e-6, inv_pi = 0.3183098861837907, inf = __builtin_huge_val();
+    OldFrame st[kRenderOldMaxDepth + 1];
+    double color[3] = {0, 0, 0};
+    for (int smp = 0; smp < P.S; smp++) {
+        const size_t sample = ((size_t)i * P.W + j) * P.S + smp;
+        const size_t base = sample * (size_t)P.D;
+        const int32_t* choice = P.light_choice + sample * (size_t)P.choices;
+        unsigned n_shadow = 0;
+        double o[3] = {P.cam[0], P.cam[1], P.cam[2]};
+        const double jit = P.rand_0[base];                               // :158-159
+        double d[3] = {P.xs[j] + jit / (double)P.W - o[0], P.ys[i] + jit / (double)P.H - o[1], P.f_distance - o[2]};
+        normalize3(d);
+        int depth = 0;
+        bool resume = false;
+        double ret[3] = {0, 0, 0};
+        st[0] = OldFrame{{1, 1, 1}, {0, 0, 0}, {0, 0, 0}, 0.0, 0};
+        for (;;) {
+            OldFrame& F = st[depth];
+            bool done = false;
+            if (resume) {                                                // back from trace_path(bounce + 1), :78-80
+                resume = false;
+#pragma unroll
+                for (int k = 0; k < 3; k++) F.L[k] += (F.direct[k] + F.thr[k] * ret[k]);
+            } else if (F.bounce >= P.D) {                                // :24-25
+                done = true;
+            } else {
+                const double r0 = P.rand_0[base + F.bounce], r1 = P.rand_1[base + F.bounce];
+                F.r0 = r0;
+                int prim; double t;
+                nearest_bvh(tris, nodes, P.n_nodes, o, d, inf, prim, t);
+                if (prim < 0) { mark_unused(P.rand_0, base, F.bounce, P.D); done = true; }
+                else {
+                    const lt_surface_material M = P.mats[prim];
+                    double n[3] = {tris[prim].n[0], tris[prim].n[1], tris[prim].n[2]};
+                    const double X[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+                    if (M.is_light && F.bounce == 0) {                   // :45-46
+#pragma unroll
+                        for (int k = 0; k < 3; k++) F.L[k] += M.emission * F.thr[k];
+                    }
+                    bool inside = false;
+                    if (dot3(n, d) > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; inside = true; }
+                    if (M.is_diffuse) {
+                        if (!shadow_direct(P, tris, nodes, X, n, M, choice[n_shadow % (unsigned)P.choices], F.direct))
+                            F.direct[0] = F.direct[1] = F.direct[2] = 0;
+                        n_shadow++;
+                        double o4[4];
+                        cosine_hemi(n, d, r0, r1, o4);
+                        if (o4[3] == 0) { mark_unused(P.rand_0, base, F.bounce + 1, P.D); done = true; }
+                        else {
+                            const double cos_theta = o4[0] * n[0] + o4[1] * n[1] + o4[2] * n[2];
+#pragma unroll
+                            for (int k = 0; k < 3; k++) {
+                                F.thr[k] *= (M.diffuse[k] * inv_pi) * cos_theta / o4[3];
+                                o[k] = X[k] + eps * o4[k];
+                                d[k] = o4[k];
+                            }
+                            const int child = F.bounce + 1;
+                            depth++;                                     // trace_path(scene, ..., ray, bounce + 1, ...), :78
+                            st[depth] = OldFrame{{1, 1, 1}, {0, 0, 0}, {0, 0, 0}, 0.0, child};
+                            continue;
+                        }
+                    } else if (M.is_mirror || M.transmission > 0.0) {
+                        specular_bounce(M, X, n, inside, r0, o, d);
+                    } else done = true;                                  // :122-124
+                }
+            }
+            if (!done && F.bounce > 3) {                                 // :127-133
+                const double rr = ::fmax(0.05, 1 - F.thr[1]);
+                if (F.r0 < rr) { mark_unused(P.rand_0, base, F.bounce + 1, P.D); done = true; }
+                else { F.thr[0] /= 1 - rr; F.thr[1] /= 1 - rr; F.thr[2] /= 1 - rr; }
+            }
+            if (!done) { F.bounce++; continue; }
+            ret[0] = F.L[0]; ret[1] = F.L[1]; ret[2] = F.L[2];          // return light, :137
+            if (depth == 0) break;
+            depth--;
+            resume = true;
+        }
+        color[0] += ret[0]; color[1] += ret[1]; color[2] += ret[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {                                       // :166-167
+        double c = color[k] / (double)P.S;
+        c = c < 0 ? 0.0 : (c > 1 ? 1.0 : c);
+        P.image[(size_t)pix * 3 + k] = c;
+    }
+}
+
 hipError_t launch_render_surface(const RenderParams& P, hipStream_t s)
 {
     const int n = P.W * P.H;
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_render_surface, dim3((n + 63) / 64), dim3(64), 0, s, P);
+    if (P.variant == 1) hipLaunchKernelGGL(k_render_surface_old, dim3((n + 63) / 64), dim3(64), 0, s, P);
+    else hipLaunchKernelGGL(k_render_surface, dim3((n + 63) / 64), dim3(64), 0, s, P);
     return hipGetLastError();
 }
 

@@ -333,3 +333,124 @@ int lto_render_surface(const lto_scene* sc, const lt_surface_material* mats, con
     release_f64(&Wd);
     return 0;
 }
+
+
+/* ---- the recursive ancestor, S/path_tracing_old.py (the integrator examples/LTS.ipynb calls) ---- */
+typedef struct old_env {
+    const world_f64* Wd; const lto_scene* sc;
+    const lt_surface_material* mats; const lt_point_light* lights;
+    double* rand_0; const double* rand_1;
+    const int32_t* choice; int choices; unsigned n_shadow;
+    size_t base; int D;
+} old_env;
+
+/* trace_path(scene, primitives, bvh, ray, bounce, rand_idx), :17-137; the ray (o, d) is the caller's object */
+static void trace_path_old(old_env* E, double o[3], double d[3], int bounce, double L[3])
+{
+    const double eps = 1e-6, inv_pi = 0.3183098861837907;
+    double thr[3] = {1, 1, 1};
+    L[0] = L[1] = L[2] = 0;
+    for (;;) {
+        if (bounce >= E->D) break;                                             /* :24-25 */
+        const double r0 = E->rand_0[E->base + bounce], r1 = E->rand_1[E->base + bounce];
+        int prim; double t;
+        nearest_bvh_f64(E->Wd->tris, E->Wd->nodes, E->sc->n_nodes, o, d, INFINITY, &prim, &t);
+        if (prim < 0) { mark_unused(E->rand_0, E->base, bounce, E->D); break; }  /* :34-38 */
+        const lt_surface_material* M = &E->mats[prim];
+        double n[3] = {E->Wd->tris[prim].n[0], E->Wd->tris[prim].n[1], E->Wd->tris[prim].n[2]};
+        const double X[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+        if (M->is_light && bounce == 0) for (int k = 0; k < 3; k++) L[k] += M->emission * thr[k];   /* :45-46 */
+        int inside = 0;
+        if (dot3_f64(n, d) > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; inside = 1; }
+        if (M->is_diffuse) {
+            double direct[3] = {0, 0, 0};                                      /* cast_one_shadow_ray, :56 */
+            const double so[3] = {X[0] + eps * n[0], X[1] + eps * n[1], X[2] + eps * n[2]};
+            const lt_point_light* lt = &E->lights[E->choice[E->n_shadow % (unsigned)E->choices]];
+            E->n_shadow++;
+            double v[3] = {lt->source[0] - so[0], lt->source[1] - so[1], lt->source[2] - so[2]};
+            const double mag = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            const double sd[3] = {v[0] / mag, v[1] / mag, v[2] / mag};
+            int sp; double st;
+            nearest_bvh_f64(E->Wd->tris, E->Wd->nodes, E->sc->n_nodes, so, sd, INFINITY, &sp, &st);
+            if (st >= mag - eps) {
+                const double cos_t = dot3_f64(n, sd);
+                const double nsd[3] = {-sd[0], -sd[1], -sd[2]};
+                const double cos_p = dot3_f64(lt->normal, nsd);
+                const double geom = fabs(cos_t * cos_p) / (mag * mag);
+                for (int k = 0; k < 3; k++) direct[k] = (lt->radiance[k] * (M->diffuse[k] * inv_pi)) * geom * lt->total_area;
+            }
+            double o4[4];
+            cosine_hemi_f64(n, d, r0, r1, o4);                                 /* :59 */
+            if (o4[3] == 0) { mark_unused(E->rand_0, E->base, bounce + 1, E->D); break; }   /* :61-64 */
+            const double cos_theta = o4[0] * n[0] + o4[1] * n[1] + o4[2] * n[2];
+            for (int k = 0; k < 3; k++) {
+                thr[k] *= (M->diffuse[k] * inv_pi) * cos_theta / o4[3];
+                o[k] = X[k] + eps * o4[k];
+                d[k] = o4[k];
+            }
+            double Lc[3];
+            trace_path_old(E, o, d, bounce + 1, Lc);                           /* :78: same ray object */
+            for (int k = 0; k < 3; k++) L[k] += (direct[k] + thr[k] * Lc[k]);  /* :78-80 */
+        } else if (M->is_mirror) {
+            double r[3]; reflect_f64(d, n, r);
+            for (int k = 0; k < 3; k++) { o[k] = X[k] + eps * n[k]; d[k] = r[k]; }
+        } else if (M->transmission > 0.0) {                                    /* :88-120 */
+            const double n1 = inside ? M->ior : 1.0, n2 = inside ? 1.0 : M->ior;
+            const double R0 = ((n1 - n2) / (n1 + n2)) * ((n1 - n2) / (n1 + n2));
+            const double theta = dot3_f64(d, n);
+            const double refl_prob = R0 + (1 - R0) * pow(1 - cos(theta), 5.0);
+            double Nr = M->ior;
+            if (theta > 0) Nr = 1 / Nr;
+            Nr = 1 / Nr;
+            const double cos_theta = -theta;
+            const double rad = 1 - (Nr * Nr) * (1 - cos_theta * cos_theta);
+            if (rad > 0 && r0 > refl_prob) {
+                const double kk = Nr * cos_theta - sqrt(rad);
+                double tr[3] = {d[0] * Nr + n[0] * kk, d[1] * Nr + n[1] * kk, d[2] * Nr + n[2] * kk};
+                normalize3_f64(tr);
+                for (int k = 0; k < 3; k++) { o[k] = X[k] - eps * n[k]; d[k] = tr[k]; }
+            } else {
+                double r[3]; reflect_f64(d, n, r);
+                for (int k = 0; k < 3; k++) { o[k] = X[k] + eps * n[k]; d[k] = r[k]; }
+            }
+        } else break;
+        if (bounce > 3) {                                                      /* :127-133 */
+            const double rr = fmax(0.05, 1 - thr[1]);
+            if (r0 < rr) { mark_unused(E->rand_0, E->base, bounce + 1, E->D); break; }
+            thr[0] /= 1 - rr; thr[1] /= 1 - rr; thr[2] /= 1 - rr;
+        }
+        bounce++;
+    }
+}
+
+int lto_render_surface_old(const lto_scene* sc, const lt_surface_material* mats, const lt_point_light* lights,
+                           int n_lights, int W, int H, int S, int D, const double camera[3], double f_distance,
+                           const double* xs, const double* ys, double* rand_0, const double* rand_1,
+                           const int32_t* light_choice, int choices_per_sample, double* image)
+{
+    if (!sc || sc->n_tris <= 0 || !mats || !lights || n_lights <= 0 || choices_per_sample <= 0) return LT_E_INVALID;
+    world_f64 Wd; prepare_f64(&Wd, sc);
+    old_env E = {&Wd, sc, mats, lights, rand_0, rand_1, NULL, choices_per_sample, 0, 0, D};
+    for (int i = 0; i < H; i++) for (int j = 0; j < W; j++) {
+        double color[3] = {0, 0, 0};
+        for (int smp = 0; smp < S; smp++) {
+            const size_t sample = ((size_t)i * W + j) * S + smp;
+            E.base = sample * (size_t)D;
+            E.choice = light_choice + sample * (size_t)choices_per_sample;
+            E.n_shadow = 0;
+            double o[3] = {camera[0], camera[1], camera[2]};
+            const double jit = rand_0[E.base];                                 /* :158-159 */
+            double d[3] = {xs[j] + jit / (double)W - o[0], ys[i] + jit / (double)H - o[1], f_distance - o[2]};
+            normalize3_f64(d);
+            double L[3];
+            trace_path_old(&E, o, d, 0, L);
+            color[0] += L[0]; color[1] += L[1]; color[2] += L[2];
+        }
+        for (int k = 0; k < 3; k++) {                                          /* :166-167 */
+            double c = color[k] / (double)S;
+            image[((size_t)i * W + j) * 3 + k] = c < 0 ? 0.0 : (c > 1 ? 1.0 : c);
+        }
+    }
+    release_f64(&Wd);
+    return 0;
+}

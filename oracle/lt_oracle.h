@@ -89,6 +89,13 @@ int lto_render_surface(const lto_scene* sc, const lt_surface_material* mats, con
                        int n_lights, int width, int height, int samples, int max_depth, const double camera[3],
                        double f_distance, const double* xs, const double* ys, double* rand_0, const double* rand_1,
                        const int32_t* light_choice, double* image);
+/* The recursive ancestor examples/LTS.ipynb calls (S/path_tracing_old.py:17-171), written as the recursion it is;
+ * light_choice [H][W][S][choices_per_sample] is consumed in depth-first shadow-ray order; image is overwritten.
+ * Pinned by fixture G9. */
+int lto_render_surface_old(const lto_scene* sc, const lt_surface_material* mats, const lt_point_light* lights,
+                           int n_lights, int width, int height, int samples, int max_depth, const double camera[3],
+                           double f_distance, const double* xs, const double* ys, double* rand_0, const double* rand_1,
+                           const int32_t* light_choice, int choices_per_sample, double* image);
 
 #ifdef __cplusplus
 }

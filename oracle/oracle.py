@@ -202,9 +202,10 @@ class PointLight(C.Structure):
                 ("total_area", C.c_double)]
 
 
-def render_surface(scene, mats, lights, camera, f_distance, xs, ys, rand_0, rand_1, light_choice, image):
+def render_surface(scene, mats, lights, camera, f_distance, xs, ys, rand_0, rand_1, light_choice, image, old=False):
     """mats: [T, 9] rows (diffuse[3], emission, ior, transmission, is_diffuse, is_mirror, is_light);
-    lights: [L, 10] rows (source[3], normal[3], radiance[3], total_area).  rand_0 and image updated in place."""
+    lights: [L, 10] rows (source[3], normal[3], radiance[3], total_area).  rand_0 and image updated in place.
+    old=True: the recursive path_tracing_old integrator, light_choice [H, W, S, choices_per_sample]."""
     s = scene._c()
     mats = np.asarray(mats, dtype=np.float64); lights = np.asarray(lights, dtype=np.float64)
     ma = (SurfaceMaterial * len(mats))()
@@ -220,8 +221,15 @@ def render_surface(scene, mats, lights, camera, f_distance, xs, ys, rand_0, rand
     r1 = np.ascontiguousarray(rand_1, dtype=np.float64)
     xs = np.ascontiguousarray(xs, dtype=np.float64); ys = np.ascontiguousarray(ys, dtype=np.float64)
     cam = (C.c_double * 3)(*[float(x) for x in np.asarray(camera).ravel()[:3]])
-    rc = lib().lto_render_surface(C.byref(s), ma, la, C.c_int(len(lights)), C.c_int(W), C.c_int(H), C.c_int(S), C.c_int(D),
-                                  cam, C.c_double(f_distance), _dp(xs), _dp(ys), _dp(rand_0), _dp(r1), _ip(lc), _dp(image))
+    if old:
+        assert lc.shape[:3] == (H, W, S)
+        rc = lib().lto_render_surface_old(C.byref(s), ma, la, C.c_int(len(lights)), C.c_int(W), C.c_int(H), C.c_int(S),
+                                          C.c_int(D), cam, C.c_double(f_distance), _dp(xs), _dp(ys), _dp(rand_0), _dp(r1),
+                                          _ip(lc), C.c_int(lc.shape[3]), _dp(image))
+    else:
+        rc = lib().lto_render_surface(C.byref(s), ma, la, C.c_int(len(lights)), C.c_int(W), C.c_int(H), C.c_int(S),
+                                      C.c_int(D), cam, C.c_double(f_distance), _dp(xs), _dp(ys), _dp(rand_0), _dp(r1),
+                                      _ip(lc), _dp(image))
     if rc != 0:
         raise RuntimeError("lto_render_surface failed: %d" % rc)
     return image

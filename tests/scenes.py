@@ -159,3 +159,11 @@ def check_g8_image(img, rand_0_after, g8, name):
     bad = int((np.abs(img - asis).max(axis=2) > 1e-9).sum())
     assert bad <= 8, "%d pixels differ from the reference-as-shipped render" % bad
     assert img.sum() > 10 and (img.max(axis=2) > 0.2).sum() > 50
+
+
+def check_g9_image(img, rand_0_after, g9, name):
+    """path_tracing_old.render_scene as the reference ran it (correct nearest hit), incl. the markers in rand_0."""
+    np.testing.assert_allclose(img, g9[name + "_image"], rtol=1e-9, atol=1e-12)
+    marks = np.isinf(g9[name + "_rand_0_after"])
+    assert np.array_equal(np.isinf(rand_0_after), marks) and marks.sum() > 100
+    assert g9[name + "_shadow_rays"].max() > 4 and img.sum() > 10   # the recursion really branched

@@ -434,6 +434,68 @@ def test_g8_surface_render(ctx, golden_dir, name):
     np.testing.assert_allclose(img, 2 * g8[name + "_brute_image"], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("name", ["glass", "mirror"])
+def test_g9_recursive_surface_render(ctx, golden_dir, name):
+    """path_tracing_old.render_scene (:17-171, the integrator examples/LTS.ipynb calls) through lt_render_surface_old
+    against the image the REFERENCE produced from the same tables (G9); the recursion runs on a per-lane stack."""
+    from light_transport_amd import _lib
+    g9 = load(golden_dir, "g9_render_old.npz")
+    inp = S.g8_inputs(g9, name)
+    m = inp["mesh"]
+    ctx.set_mesh(m["verts"], m["med_front"], m["med_back"], m["nodes"])
+    mats = (_lib.SurfaceMaterial * len(inp["mats"]))()
+    for i, r in enumerate(inp["mats"]):
+        mats[i].diffuse[:] = list(r[:3]); mats[i].emission, mats[i].ior, mats[i].transmission = r[3], r[4], r[5]
+        mats[i].is_diffuse, mats[i].is_mirror, mats[i].is_light = int(r[6]), int(r[7]), int(r[8])
+    lights = (_lib.PointLight * len(inp["lights"]))()
+    for i, r in enumerate(inp["lights"]):
+        lights[i].source[:] = list(r[:3]); lights[i].normal[:] = list(r[3:6]); lights[i].radiance[:] = list(r[6:9])
+        lights[i].total_area = r[9]
+    ctx.set_surface_materials(mats); ctx.set_lights(lights)
+    H, W, _, _ = inp["shape"]
+    img = np.full((H, W, 3), 9.0); r0 = inp["rand_0"].copy()       # overwritten, not accumulated (:167)
+    ctx.render_surface(inp["camera"], inp["f_distance"], inp["xs"], inp["ys"], r0, np.ascontiguousarray(inp["rand_1"]),
+                       inp["light_choice"], img, old=True)
+    S.check_g9_image(img, r0, g9, name)
+    # deeper than the fixture: the unrolled recursion against the oracle's real recursion, wrapped choice table (Q = 5)
+    rs = np.random.RandomState(5)
+    Hh, Ww, Ss, Dd = 12, 18, 2, 14
+    r0 = rs.rand(Hh, Ww, Ss, Dd); r1 = rs.rand(Hh, Ww, Ss, Dd); lc = rs.randint(0, len(inp["lights"]), size=(Hh, Ww, Ss, 5))
+    xs, ys = np.linspace(-1, 1, Ww), np.linspace(1 / (Ww / Hh), -1 / (Ww / Hh), Hh)
+    img, imgo, r0o = np.zeros((Hh, Ww, 3)), np.zeros((Hh, Ww, 3)), r0.copy()
+    ctx.render_surface(inp["camera"], inp["f_distance"], xs, ys, r0, r1, lc, img, old=True)
+    sc = O.OracleScene([(0, 0, 0, 1)], (1, 1, 1), (0, 0, 0), (1, 1, 1), mesh=inp["mesh"])
+    O.render_surface(sc, inp["mats"], inp["lights"], inp["camera"], inp["f_distance"], xs, ys, r0o, r1, lc, imgo, old=True)
+    np.testing.assert_allclose(img, imgo, rtol=1e-9, atol=1e-12)
+    assert np.array_equal(np.isinf(r0), np.isinf(r0o))
+    with pytest.raises(_lib.LtError):
+        ctx.render_surface(inp["camera"], inp["f_distance"], xs, ys, np.zeros((Hh, Ww, 1, 25)), np.zeros((Hh, Ww, 1, 25)),
+                           np.zeros((Hh, Ww, 1, 3), np.int32), img, old=True)     # max_depth > 24
+
+
+def test_render_scene_old_object_api(ctx):
+    """The LTS.ipynb call: path_tracing_old.render_scene(scene, primitives, bvh) -> ndarray (overwrites scene.image)."""
+    from light_transport_amd.src import constants as K, cornell_box as cb, bvh_new as B
+    from light_transport_amd.src.light_samples import generate_area_light_samples
+    from light_transport_amd.src.material import Material
+    from light_transport_amd.src.path_tracing_old import render_scene
+    from light_transport_amd.src.scene import Scene
+    depth = 7.5
+    surf = Material(color=K.WHITE_2, shininess=30, reflection=0.1, ior=1.521, transmission=1)
+    src = Material(color=K.WHITE, shininess=1, reflection=0.9, ior=1.5, emission=200)
+    lq = cb.get_light_quad(depth, src)
+    objects = cb.get_cornell_box(depth, surf, surf, surf) + cb.get_cone(K.GLASS_MAT) + lq
+    np.random.seed(1)
+    lights = generate_area_light_samples(lq[0], lq[1], src, 40, 4)
+    ordered, linear = B.build_linear_bvh(objects)
+    np.random.seed(0)
+    sc = Scene(camera=np.array([0, 0, depth + 0.5, 1.0]), lights=lights, width=24, height=16, max_depth=5,
+               f_distance=depth, number_of_samples=3)
+    sc.image[:] = 5.0
+    img = render_scene(sc, ordered, linear, ctx=ctx)
+    assert img is sc.image and img.shape == (16, 24, 3) and 0 < img.max() <= 1.0 and np.isinf(sc.rand_0).any()
+
+
 def test_render_scene_object_api(ctx, golden_dir):
     """The reference-style call: Scene + primitives + linear BVH -> ndarray."""
     from light_transport_amd.src import constants as K, cornell_box as cb, bvh_new as B

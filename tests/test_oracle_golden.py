@@ -141,6 +141,19 @@ def test_g8_surface_render(golden_dir, name):
     S.check_g8_image(img, r0, g8, name)
 
 
+@pytest.mark.parametrize("name", ["glass", "mirror"])
+def test_g9_recursive_surface_render(golden_dir, name):
+    """The recursive integrator of examples/LTS.ipynb (path_tracing_old.render_scene) reproduced by the oracle."""
+    g9 = load(golden_dir, "g9_render_old.npz")
+    inp = S.g8_inputs(g9, name)
+    sc = O.OracleScene([(0, 0, 0, 1)], (1, 1, 1), (0, 0, 0), (1, 1, 1), mesh=inp["mesh"])
+    H, W, _, _ = inp["shape"]
+    img = np.full((H, W, 3), 9.0); r0 = inp["rand_0"].copy()       # the image is overwritten, not accumulated (:167)
+    O.render_surface(sc, inp["mats"], inp["lights"], inp["camera"], inp["f_distance"], inp["xs"], inp["ys"], r0,
+                     inp["rand_1"], inp["light_choice"], img, old=True)
+    S.check_g9_image(img, r0, g9, name)
+
+
 # ------------------------------------------------------------------ part 2
 def test_xorwow_known_answer():
     """Marsaglia's xorwow with rocRAND's seeding: seed 0 state is the published
