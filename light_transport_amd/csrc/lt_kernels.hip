@@ -44,6 +44,15 @@ namespace ltk {
 // correct rounding; the walk only ever needs -ln(xi) for xi in [2^-53, 1], sin/cos of a turn fraction in (0, 1],
 // sqrt on [0, 1] and quotients of well-scaled numbers.  These versions are accurate to ~1-2 ulp (checked against
 // the host libm in tests/test_gpu_parity.py through lt_eval) at 35 / 38 / 9 / 8 instructions.
+// a * b + k with the constant k in a scalar register pair: ONE v_fma_f64.  Left to itself the compiler parks
+// polynomial coefficients in VGPRs and spends a v_mov_b64 + v_fmac_f64 per Horner step (the VOP2 form accumulates
+// into its addend, and an f64 literal operand only carries the high dword).
+LT_DEV double fma_k(double a, double b, double k)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
 LT_DEV double fast_rcp(double d)
 {
     double r = __builtin_amdgcn_rcp(d);                 // v_rcp_f64: ~26 good bits
@@ -79,9 +88,9 @@ LT_DEV double neg_log_unit(double x)                     // -ln(x), x in [2^-53,
     const double z = s * s;
     // ln(m) = 2 s (1 + z/3 + z^2/5 + ... + z^10/21); the truncated tail is < 3e-18 relative
     double p = 1.0 / 21.0;
-    p = __builtin_fma(p, z, 1.0 / 19.0); p = __builtin_fma(p, z, 1.0 / 17.0); p = __builtin_fma(p, z, 1.0 / 15.0);
-    p = __builtin_fma(p, z, 1.0 / 13.0); p = __builtin_fma(p, z, 1.0 / 11.0); p = __builtin_fma(p, z, 1.0 / 9.0);
-    p = __builtin_fma(p, z, 1.0 / 7.0);  p = __builtin_fma(p, z, 1.0 / 5.0);  p = __builtin_fma(p, z, 1.0 / 3.0);
+    p = fma_k(p, z, 1.0 / 19.0); p = fma_k(p, z, 1.0 / 17.0); p = fma_k(p, z, 1.0 / 15.0);
+    p = fma_k(p, z, 1.0 / 13.0); p = fma_k(p, z, 1.0 / 11.0); p = fma_k(p, z, 1.0 / 9.0);
+    p = fma_k(p, z, 1.0 / 7.0);  p = fma_k(p, z, 1.0 / 5.0);  p = fma_k(p, z, 1.0 / 3.0);
     const double lnm = __builtin_fma(2.0 * s * z, p, 2.0 * s);
     const double de = (double)e;
     // ln 2 split so that e * hi is exact for |e| <= 53
@@ -94,20 +103,20 @@ LT_DEV void sincos_turn_f64(double xi, double* sn, double* cs)  // sin, cos of 2
     const double a = (t - qf) * 1.57079632679489661923;  // (t - qf) exact, |a| <= pi/4
     const double z = a * a;
     double ps = -7.6471637318198164759e-13;              // -1/15!
-    ps = __builtin_fma(ps, z, 1.6059043836821614599e-10);   //  1/13!
-    ps = __builtin_fma(ps, z, -2.5052108385441718775e-08);  // -1/11!
-    ps = __builtin_fma(ps, z, 2.7557319223985890653e-06);   //  1/9!
-    ps = __builtin_fma(ps, z, -1.9841269841269841270e-04);  // -1/7!
-    ps = __builtin_fma(ps, z, 8.3333333333333333333e-03);   //  1/5!
-    ps = __builtin_fma(ps, z, -1.6666666666666666667e-01);  // -1/3!
+    ps = fma_k(ps, z, 1.6059043836821614599e-10);   //  1/13!
+    ps = fma_k(ps, z, -2.5052108385441718775e-08);  // -1/11!
+    ps = fma_k(ps, z, 2.7557319223985890653e-06);   //  1/9!
+    ps = fma_k(ps, z, -1.9841269841269841270e-04);  // -1/7!
+    ps = fma_k(ps, z, 8.3333333333333333333e-03);   //  1/5!
+    ps = fma_k(ps, z, -1.6666666666666666667e-01);  // -1/3!
     const double s = __builtin_fma(a * z, ps, a);
     double pc = 4.7794773323873852974e-14;               //  1/16!
-    pc = __builtin_fma(pc, z, -1.1470745597729724714e-11);  // -1/14!
-    pc = __builtin_fma(pc, z, 2.0876756987868098979e-09);   //  1/12!
-    pc = __builtin_fma(pc, z, -2.7557319223985890653e-07);  // -1/10!
-    pc = __builtin_fma(pc, z, 2.4801587301587301587e-05);   //  1/8!
-    pc = __builtin_fma(pc, z, -1.3888888888888888889e-03);  // -1/6!
-    pc = __builtin_fma(pc, z, 4.1666666666666666667e-02);   //  1/4!
+    pc = fma_k(pc, z, -1.1470745597729724714e-11);  // -1/14!
+    pc = fma_k(pc, z, 2.0876756987868098979e-09);   //  1/12!
+    pc = fma_k(pc, z, -2.7557319223985890653e-07);  // -1/10!
+    pc = fma_k(pc, z, 2.4801587301587301587e-05);   //  1/8!
+    pc = fma_k(pc, z, -1.3888888888888888889e-03);  // -1/6!
+    pc = fma_k(pc, z, 4.1666666666666666667e-02);   //  1/4!
     pc = __builtin_fma(pc, z, -0.5);
     const double c = __builtin_fma(pc, z, 1.0);
     const int q = (int)qf & 3;                           // quadrant rotation
@@ -529,13 +538,16 @@ constexpr unsigned kPacket = 64;  // photon ids taken from the global queue per 
 // minimum waves per SIMD the register allocator must leave room for (occupancy is what hides the latency of the
 // dependent f64 / transcendental chains once deposition no longer paces the walk)
 #ifndef LT_F64_WAVES
-#define LT_F64_WAVES 3
+#define LT_F64_WAVES 3        // f64 mesh walks: 4 would spill ~80 B per lane
+#endif
+#ifndef LT_F64_SLAB_WAVES
+#define LT_F64_SLAB_WAVES 4   // f64 slab walks fit 128 VGPRs without scratch since the polynomial constants live in SGPRs
 #endif
 #ifndef LT_F32_WAVES
 #define LT_F32_WAVES 5
 #endif
 template <typename R, int GEOM, bool TABLE, int TALLY>
-__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? LT_F64_WAVES : (GEOM == 0 ? LT_F32_WAVES : 4))) walk_kernel(const WalkParams P)
+__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (GEOM == 0 ? LT_F64_SLAB_WAVES : LT_F64_WAVES) : (GEOM == 0 ? LT_F32_WAVES : 4))) walk_kernel(const WalkParams P)
 {
     constexpr bool MESH = GEOM != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -719,8 +731,14 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? LT_F64_WAVES : (GEOM ==
                 // ---- hop: distance to the next boundary ----
                 R tb = inf; int hit_tri = -1;
                 if constexpr (!MESH) {
-                    if (uz > 0) tb = (s_zb[cur + 1] - pz) / uz;
-                    else if (uz < 0) tb = (s_zb[cur] - pz) / uz;
+                    if (uz != 0) {
+                        const R dz = (uz > 0 ? s_zb[cur + 1] : s_zb[cur]) - pz;   // sign of uz, or 0
+                        // A hop that ends well inside the layer needs no quotient: |dz| > s |uz| (1 + d) with
+                        // d >= 8 ulp implies fl(dz / uz) > s, so `tb <= s` below is false either way and tb is
+                        // not read.  Only lanes within a step of an interface pay for the IEEE division.
+                        const R guard = sizeof(R) == 8 ? (R)(1.0 + 1e-12) : (R)(1.0 + 1e-5);
+                        if (!(Mx<R>::abs(dz) > s * Mx<R>::abs(uz) * guard)) tb = dz / uz;
+                    }
                 } else {
                     // clearance grid: every triangle is farther than `c` from every point of this cell, so a hop of
                     // length s < c ends before any surface and the traversal is skipped (same result, no query)
