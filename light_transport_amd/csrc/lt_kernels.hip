@@ -53,6 +53,14 @@ LT_DEV double fma_k(double a, double b, double k)
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
     return r;
 }
+// x * k + k, one v_fma_f64 with k read twice from the same scalar pair: the (0, 1] uniform conversions of
+// rocrand_uniform.h:97-109 (k = 2^-32 / 2^-53), which otherwise cost two v_mov_b32 to seed a v_fmac_f64
+LT_DEV double fma_kk(double x, double k)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %2" : "=v"(r) : "v"(x), "s"(k));
+    return r;
+}
 LT_DEV double fast_rcp(double d)
 {
     double r = __builtin_amdgcn_rcp(d);                 // v_rcp_f64: ~26 good bits
@@ -66,18 +74,23 @@ LT_DEV double fast_div(double a, double b)
     const double q = a * r;
     return __builtin_fma(__builtin_fma(-b, q, a), r, q); // one residual correction
 }
-LT_DEV double sqrt01(double x)                           // x in [0, 1] (0 exactly allowed)
+LT_DEV double sqrt_core(double x, double y)              // y ~ 1/sqrt(x) to ~26 bits (v_rsq_f64)
 {
-    double y = __builtin_amdgcn_rsq(x > 0.0 ? x : 1.0);  // v_rsq_f64
     double g = x * y, h = 0.5 * y;
     double r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
     r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
     const double d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    return x > 0.0 ? g : 0.0;
+    return __builtin_fma(d, h, g);
 }
+LT_DEV double sqrt01(double x)                           // x in [0, 1]; 0 (and a rounding-negative x) gives 0
+{
+    const double xc = __builtin_fmax(x, 0.0);
+    // the seed of 0 is taken at 1e-300 (finite); every product with x = 0 is then an exact 0, no select needed
+    return sqrt_core(xc, __builtin_amdgcn_rsq(__builtin_fmax(xc, 1e-300)));
+}
+LT_DEV double sqrt_pos(double x) { return sqrt_core(x, __builtin_amdgcn_rsq(x)); }   // x > 0 known
 LT_DEV double neg_log_unit(double x)                     // -ln(x), x in [2^-53, 1]
 {
     int e = __builtin_amdgcn_frexp_exp(x);
@@ -130,27 +143,36 @@ template <> struct Mx<double> {
     static LT_DEV double log(double x) { return ::log(x); }
     static LT_DEV double sqrt(double x) { return ::sqrt(x); }
     static LT_DEV double abs(double x) { return ::fabs(x); }
+    static LT_DEV double clamp_unit(double c) { return __builtin_fmax(__builtin_fmin(c, 1.0), -1.0); }
     static LT_DEV double sin(double x) { return ::sin(x); }
     static LT_DEV double cos(double x) { return ::cos(x); }
     // the hot-loop forms (restricted ranges, see above)
     static LT_DEV double neg_log(double xi) { return neg_log_unit(xi); }
     static LT_DEV double sqrt_unit(double x) { return sqrt01(x); }
+    static LT_DEV double sqrt_pos(double x) { return ltk::sqrt_pos(x); }
     static LT_DEV double quot(double a, double b) { return fast_div(a, b); }
     static LT_DEV void sincos_turn(double xi, double* s, double* c) { sincos_turn_f64(xi, s, c); }
     static LT_DEV double inf() { return __builtin_huge_val(); }
-    static LT_DEV double uniform(rocrand_state_xorwow* st) { return rocrand_uniform_double(st); }
+    // rocrand_uniform_double (rocrand_uniform.h:102-109, 454-460): two draws, 53 bits, (0, 1]
+    static LT_DEV double uniform(rocrand_state_xorwow* st)
+    {
+        const unsigned v1 = rocrand(st), v2 = rocrand(st);
+        return fma_kk((double)(((unsigned long long)(v2 >> 11) << 32) | v1), 1.1102230246251565404e-16);
+    }
     // 32-bit-resolution uniform in (0,1] from ONE draw (rocrand_uniform.h:97-100); used for the three
     // decision/angle uniforms of a step, where 2^-32 is far below any physical resolution
-    static LT_DEV double uniform32(rocrand_state_xorwow* st) { return rocrand_device::detail::uniform_distribution_double(rocrand(st)); }
+    static LT_DEV double uniform32(rocrand_state_xorwow* st) { return fma_kk((double)rocrand(st), 2.3283064365386962891e-10); }
 };
 template <> struct Mx<float> {
     static LT_DEV float log(float x) { return ::logf(x); }
     static LT_DEV float sqrt(float x) { return ::sqrtf(x); }
     static LT_DEV float abs(float x) { return ::fabsf(x); }
+    static LT_DEV float clamp_unit(float c) { return __builtin_fmaxf(__builtin_fminf(c, 1.0f), -1.0f); }
     static LT_DEV float sin(float x) { return ::sinf(x); }
     static LT_DEV float cos(float x) { return ::cosf(x); }
     static LT_DEV float neg_log(float xi) { return -::logf(xi); }
-    static LT_DEV float sqrt_unit(float x) { return ::sqrtf(x); }
+    static LT_DEV float sqrt_unit(float x) { return ::sqrtf(__builtin_fmaxf(x, 0.0f)); }
+    static LT_DEV float sqrt_pos(float x) { return ::sqrtf(x); }
     static LT_DEV float quot(float a, float b) { return a / b; }
     static LT_DEV void sincos_turn(float xi, float* s, float* c) { ::sincospif(2.0f * xi, s, c); }
     static LT_DEV float inf() { return __builtin_huge_valf(); }
@@ -297,9 +319,7 @@ template <typename R> LT_DEV R hg_sample(R xi, R g, R one_m_g2, R one_p_g2, R in
         R t = Mx<R>::quot(one_m_g2, (R)1 - g + (R)2 * g * xi);
         c = (one_p_g2 - t * t) * inv_2g;
     }
-    c = c > 1 ? (R)1 : c;
-    c = c < -1 ? (R)-1 : c;
-    return c;
+    return Mx<R>::clamp_unit(c);   // [-1, 1]
 }
 
 // create_orthonormal_system, S/utils.py:72-80
@@ -379,14 +399,14 @@ template <typename R> LT_DEV R boundary(const R* d, const R* nf, R n1, R n2, R* 
 template <typename R> LT_DEV void spin(R* u, R ct, R xi_phi)
 {
     R st2 = (R)1 - ct * ct;
-    R st = Mx<R>::sqrt_unit(st2 > 0 ? st2 : (R)0);
+    R st = Mx<R>::sqrt_unit(st2);                       // clamps a rounding-negative 1 - ct^2 to 0 itself
     R sp, cp; Mx<R>::sincos_turn(xi_phi, &sp, &cp);
     R ux = u[0], uy = u[1], uz = u[2];
     if (Mx<R>::abs(uz) > (R)0.99999) {
         u[0] = st * cp; u[1] = st * sp; u[2] = uz >= 0 ? ct : -ct;
     } else {
         R t2 = (R)1 - uz * uz;
-        R tmp = Mx<R>::sqrt_unit(t2);
+        R tmp = Mx<R>::sqrt_pos(t2);                    // |uz| <= 0.99999: t2 >= 2e-5
         u[0] = Mx<R>::quot(st * (ux * uz * cp - uy * sp), tmp) + ux * ct;
         u[1] = Mx<R>::quot(st * (uy * uz * cp + ux * sp), tmp) + uy * ct;
         u[2] = -st * cp * tmp + uz * ct;
@@ -737,7 +757,12 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (GEOM == 0 ? LT_F64_SLA
                         // d >= 8 ulp implies fl(dz / uz) > s, so `tb <= s` below is false either way and tb is
                         // not read.  Only lanes within a step of an interface pay for the IEEE division.
                         const R guard = sizeof(R) == 8 ? (R)(1.0 + 1e-12) : (R)(1.0 + 1e-5);
-                        if (!(Mx<R>::abs(dz) > s * Mx<R>::abs(uz) * guard)) tb = dz / uz;
+                        const bool near = !(Mx<R>::abs(dz) > s * Mx<R>::abs(uz) * guard);
+                        if (__any(near)) {   // wave-uniform skip; the empty asm keeps the quotient from being hoisted
+                            R den = uz;      // back out and turned into a select
+                            asm volatile("" : "+v"(den));
+                            if (near) tb = dz / den;
+                        }
                     }
                 } else {
                     // clearance grid: every triangle is farther than `c` from every point of this cell, so a hop of
@@ -811,19 +836,22 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (GEOM == 0 ? LT_F64_SLA
                         record_vertex<R>(P, pid - P.photon_offset, nv, px, py, pz, ux, uy, uz, w, LT_VERTEX_VOLUME, cur, step);
                     const R dw = w * Mp->absorb;
                     const R fx = (px - gx0) * ivx, fy = (py - gy0) * ivy, fz = (pz - gz0) * ivz;
-                    if (fx >= 0 && fx < fnx && fy >= 0 && fy < fny && fz >= 0 && fz < fnz) {
-                        const unsigned vx = (unsigned)(int)fx, vy = (unsigned)(int)fy, vz = (unsigned)(int)fz;
-                        const unsigned idx = P.log_idx   // log mode: tiled index (see kTileBX); atomic mode: linear index
-                            ? (((((vz >> kTileBZ) * P.log_nty + (vy >> kTileBY)) * P.log_ntx + (vx >> kTileBX)) << kTileShift)
-                               | ((vz & 15u) << 10) | ((vy & 31u) << 5) | (vx & 31u))
-                            : (vz * (unsigned)P.ny + vy) * (unsigned)P.nx + vx;
-                        const TV q = tally_quantum<TALLY, R>(dw);
-                        if (idx == pend_idx) pend_val += q;
-                        else { f_idx = pend_idx; f_val = pend_val; pend_idx = idx; pend_val = q; }
-                        acc_abs += (double)dw;
-                    } else {
-                        acc_lost += (double)dw;
-                    }
+                    // branch-free: nearly every deposit is inside the grid, so the index is computed for all lanes
+                    // and the run-length accumulator is updated with selects
+                    const bool inside = fx >= 0 && fx < fnx && fy >= 0 && fy < fny && fz >= 0 && fz < fnz;
+                    const unsigned vx = (unsigned)(int)fx, vy = (unsigned)(int)fy, vz = (unsigned)(int)fz;
+                    const unsigned idx = P.log_idx   // log mode: tiled index (see kTileBX); atomic mode: linear index
+                        ? (((((vz >> kTileBZ) * P.log_nty + (vy >> kTileBY)) * P.log_ntx + (vx >> kTileBX)) << kTileShift)
+                           | ((vz & 15u) << 10) | ((vy & 31u) << 5) | (vx & 31u))
+                        : (vz * (unsigned)P.ny + vy) * (unsigned)P.nx + vx;
+                    const TV q = tally_quantum<TALLY, R>(dw);
+                    const bool same = inside && idx == pend_idx;
+                    const bool flush = inside && !same;
+                    f_idx = flush ? pend_idx : kNoVoxel; f_val = pend_val;
+                    pend_val = same ? pend_val + q : (flush ? q : pend_val);
+                    pend_idx = flush ? idx : pend_idx;
+                    acc_abs += inside ? (double)dw : 0.0;
+                    acc_lost += inside ? 0.0 : (double)dw;
                     w -= dw;
                     if (!(w > 0)) alive = false;
                     else {
