@@ -212,7 +212,8 @@ def main():
             w, p_, r_ = (float(np.mean([x[k] for x in stages])) for k in ("walk_ms", "partition_ms", "reduce_ms"))
             out["roofline"]["kernels"] = [
                 {"kernel": "walk_kernel", "ms": w, "bound": "valu",
-                 "note": "405 VALU instr per photon-step (PMC SQ_INSTS_VALU), 3 waves/SIMD; writes the %.1f GB deposit log" % (rec * rb / 1e9),
+                 "note": "361 VALU instr per photon-step (PMC SQ_INSTS_VALU, profiles/r01d_pmc_sq.csv), %s; writes the %.1f GB deposit log"
+                         % ("5 waves/SIMD" if args.f32_walk else "4 waves/SIMD, 96 %% VALU issue occupancy", rec * rb / 1e9),
                  "photon_steps_per_sec": steps_one_launch / (w * 1e-3)},
                 {"kernel": "k_log_part", "ms": p_, "bound": "hbm", "achieved": 2 * rb * rec / (p_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "frac": 2 * rb * rec / (p_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
