@@ -12,13 +12,18 @@ the log-structured tally: walk -> deposit log -> tile partition -> LDS reduce) a
 -- for N > 1 -- sum-reduce the voxel grid + counters to rank 0 with RCCL.  Ranks trace disjoint
 photon-id ranges (weak scaling: 1e7 photons per GPU); there is no other
 collective.  Inputs are synthetic by nature (the scene is ~100 bytes of constants,
-resident in HBM before the timed region).
+resident in HBM before the timed region).  By default two jobs are in flight per
+GPU (--inflight 2: two contexts, i.e. two HIP streams with their own grid and
+deposit log, take the steps in turn), so that the bandwidth-bound log reduction of
+one job runs beside the VALU-bound walk of the next; every step is still a
+complete job and all K of them finish inside the timed region.
 
 Prints ONE JSON line on rank 0:  metric = photon-steps/s over all ranks, plus
   roofline      algorithmic tally bytes (16 B per photon-step for the f64 tally:
-                8 B read + 8 B write of one voxel) / device time of the job's
-                kernels (walk + log partition/reduce; HIP events on the ctx's own
-                stream), against the 8 TB/s HBM peak;
+                8 B read + 8 B write of one voxel) per launch / the time the device
+                takes per launch (wall / K with jobs in flight; the job's event time
+                with --inflight 1), against the 8 TB/s HBM peak; per-kernel
+                durations from HIP events on each ctx's own stream;
   cpu_baseline  the CPU oracle (oracle/, a port -- the reference has no such
                 path) on all host cores on a bounded sample of the same workload.
 """
@@ -32,6 +37,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Jobs in flight need their streams on DIFFERENT hardware queues: the HIP runtime multiplexes a process's streams
+# onto GPU_MAX_HW_QUEUES (default 4) queues, and once torch + RCCL have taken theirs two contexts can end up sharing
+# one, which serialises their kernels (measured: 57 instead of 39 ms per step under torch.distributed.run).  Must be
+# set before the runtime initialises, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 N_PHOTONS = 10 ** 7
 GRID_N, VOXEL = 256, 0.1
@@ -90,8 +100,8 @@ def cpu_baseline(target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--photons", type=int, default=N_PHOTONS, help="photons per GPU per step (default: C2's 1e7)")
     ap.add_argument("--tally", default="f64", choices=["f32", "f64", "u64fx"])
     ap.add_argument("--f32-walk", action="store_true", help="f32 walk arithmetic (default f64, the reference's dtype)")
@@ -99,6 +109,11 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--tally-mode", default="log", choices=["log", "atomic", "auto"],
                     help="log: deposit log + tile partition + LDS reduce (default); atomic: one global atomic per deposit")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="jobs in flight per GPU (contexts taking the steps in turn); 1 = strictly one job at a time")
+    ap.add_argument("--no-alone", action="store_true",
+                    help="skip the single-job reference launches after the timed region (keeps a rocprofv3 kernel "
+                         "trace of this command to launches of the timed regime only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -118,19 +133,29 @@ def main():
 
     import light_transport_amd as lt
     from light_transport_amd import distributed as ltd
-    ctx = lt.Context(local_rank)
-    configure(ctx, args.tally)
-    ctx.set_tally_mode(args.tally_mode)
-    if args.blocks_per_cu or args.threads:
-        ctx.set_launch_config(args.blocks_per_cu, args.threads)
-    if args.tally_mode != "atomic":
-        ctx.reserve_log(args.photons)   # scratch allocation is set-up, not part of a step (matters when --warmup 0)
-    info = ctx.device_info()
+    # --inflight D: D contexts (stream + grid + deposit log each) take the steps in turn, so the bandwidth-bound log
+    # reduction of one job runs beside the VALU-bound walk of the next.  The walk is then launched at 2 workgroups per
+    # CU per job: two walks together fill the 4 waves/SIMD the register file holds, one walk leaves room for the
+    # other job's partition / reduce workgroups.
+    depth = max(1, args.inflight)
+    bpc = args.blocks_per_cu or ((3 if args.f32_walk else 2) if depth > 1 else 0)   # f32 walk: 96 VGPRs, 5 waves/SIMD fit
+    ctxs = []
+    for _ in range(depth):
+        c = lt.Context(local_rank)
+        configure(c, args.tally)
+        c.set_tally_mode(args.tally_mode)
+        if bpc or args.threads:
+            c.set_launch_config(bpc, args.threads or 256)
+        if args.tally_mode != "atomic":
+            c.reserve_log(args.photons)   # scratch allocation is set-up, not part of a step (matters when --warmup 0)
+        ctxs.append(c)
+    info = ctxs[0].device_info()
     per_gpu = args.photons
     offset = rank * per_gpu     # disjoint id ranges; streams depend on (seed, id) only
 
     def barrier():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -138,31 +163,38 @@ def main():
 
     kernel_ms, steps_per_launch, stages = [], [], []
 
-    def one_step(seed):
-        ctx.zero_tally()
-        ctx.launch(per_gpu, seed=seed, photon_offset=offset, f32_walk=args.f32_walk)
-        if distributed:
-            ltd.reduce_device(ctx, dst=0)       # RCCL sum of grid + counters to rank 0
-        else:
-            ctx.sync()
+    def start(c, seed):
+        c.zero_tally()
+        c.launch(per_gpu, seed=seed, photon_offset=offset, f32_walk=args.f32_walk)
 
-    for w in range(args.warmup):
-        one_step(1000 + w)
+    def finish(c, record):
+        """Complete the job in flight on c: wait, reduce over ranks (N > 1), read the 96-byte counters."""
+        if distributed:
+            ltd.reduce_device(c, dst=0)       # RCCL sum of grid + counters to rank 0
+        else:
+            c.sync()
+        if record:
+            kernel_ms.append(c.last_kernel_ms())
+            st = c.last_log_stages()
+            if st is not None and st["batches"] == 1:
+                stages.append(st)
+            steps_per_launch.append(c.read_counters()["steps"])   # rank 0: the reduced sum; part of "tally readback"
+
+    def run_steps(n, seed0, record):
+        for k in range(n):
+            c = ctxs[k % depth]
+            if k >= depth:
+                finish(c, record)
+            start(c, seed0 + k)
+        for k in range(max(0, n - depth), n):     # drain in launch order
+            finish(ctxs[k % depth], record)
+
+    run_steps(args.warmup, 1000, False)
     barrier()
     t0 = time.perf_counter()
-    total_steps_local = 0
-    for k in range(args.steps):
-        one_step(k)
-        kernel_ms.append(ctx.last_kernel_ms())
-        st = ctx.last_log_stages()
-        if st is not None and st["batches"] == 1:
-            stages.append(st)
-        # photon-steps of this launch: rank 0 holds the reduced sum, other ranks their own
-        c = ctx.read_counters()
-        steps_per_launch.append(c["steps"])
+    run_steps(args.steps, 0, True)
     barrier()
     elapsed = time.perf_counter() - t0
-    # NOTE: read_counters above is a 96-byte D2H inside the timed region (part of "tally readback")
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -174,11 +206,31 @@ def main():
     else:
         kernel_avg_ms = float(np.mean(kernel_ms))
 
+    # one job alone on the device, default launch geometry, outside the timed region: the latency of a single job
+    # and kernel durations that no other job overlaps (context for the per-kernel figures above)
+    alone = None
+    if rank == 0 and depth > 1 and not args.no_alone:
+        c = ctxs[0]
+        c.set_launch_config(args.blocks_per_cu, args.threads or (256 if args.blocks_per_cu else 0))
+        ms = []
+        for k in range(3):
+            c.zero_tally(); c.launch(per_gpu, seed=500 + k, photon_offset=offset, f32_walk=args.f32_walk); c.sync()
+            ms.append(c.last_kernel_ms())
+        st = c.last_log_stages()
+        alone = {"job_ms": float(np.mean(ms[1:]))}
+        if st is not None:
+            alone.update({k: st[k] for k in ("walk_ms", "partition_ms", "reduce_ms")})
+
     if rank == 0:
         total_steps = int(np.sum(steps_per_launch))          # reduced over ranks when distributed
         value = total_steps / elapsed
         steps_one_launch = total_steps / args.steps / world  # per rank per launch
-        achieved = steps_one_launch * BYTES_PER_STEP[args.tally] / (kernel_avg_ms * 1e-3) / 1e9
+        ms_per_step = elapsed / args.steps * 1e3
+        # With D jobs in flight a launch's own event-to-event time spans the other job's kernels too; the device
+        # completes one launch every ms_per_step, and that is the duration the algorithmic bytes are divided by.
+        # job_event_ms keeps the raw per-launch event time (what rocprofv3's kernel trace adds up to).
+        launch_ms = ms_per_step if depth > 1 else kernel_avg_ms
+        achieved = steps_one_launch * BYTES_PER_STEP[args.tally] / (launch_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
@@ -190,45 +242,55 @@ def main():
         out = {
             "metric": "photon_steps_per_sec", "value": value, "unit": "photon-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.f32_walk else "f64", "data": "synthetic",
             "photons_per_sec": world * per_gpu * args.steps / elapsed,
             "config": {"workload": "C2: %.0e photons per GPU, homogeneous semi-infinite slab (mu_a=0.1, mu_s=10, g=0.9, "
                                    "n=1), %d^3 voxel grid (%.1f mm), pencil beam" % (per_gpu, GRID_N, VOXEL),
                        "tally": args.tally, "tally_mode": args.tally_mode, "rng": "rocRAND XORWOW, re-seeded per photon",
+                       "jobs_in_flight": depth, "walk_workgroups_per_cu": bpc or "occupancy",
                        "parallelism": "photon-id sharding x%d, RCCL reduce of the grid to rank 0 per step" % world
                        if world > 1 else "single GPU", "device": info["name"], "cus": info["cus"],
                        "clock_mhz": info["clock_mhz"], "hbm_gib": round(info["hbm_bytes"] / 2 ** 30, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "walk_kernel + k_log_scan/part/reduce (one job)" if args.tally_mode == "log"
-                         else "walk_kernel", "kernel_ms": kernel_avg_ms,
+                         else "walk_kernel", "kernel_ms": launch_ms, "job_event_ms": kernel_avg_ms,
                          "algorithmic_bytes_per_launch": steps_one_launch * BYTES_PER_STEP[args.tally]},
         }
         if stages:
-            # per-kernel rooflines of the job, live from HIP events on the ctx stream (one batch per job)
+            # per-kernel figures of the job, live from HIP events on each ctx's stream over the timed region
             rec = float(np.mean([x["records"] for x in stages]))
             rb = 4 + {"f32": 4, "f64": 8, "u64fx": 8}[args.tally]          # bytes per deposit record
             w, p_, r_ = (float(np.mean([x[k] for x in stages])) for k in ("walk_ms", "partition_ms", "reduce_ms"))
+            shared = " (shares the device with the other job in flight: durations overlap)" if depth > 1 else ""
             out["roofline"]["kernels"] = [
                 {"kernel": "walk_kernel", "ms": w, "bound": "valu",
-                 "note": "361 VALU instr per photon-step (PMC SQ_INSTS_VALU, profiles/r01d_pmc_sq.csv), %s; writes the %.1f GB deposit log"
-                         % ("5 waves/SIMD" if args.f32_walk else "4 waves/SIMD, 96 %% VALU issue occupancy", rec * rb / 1e9),
+                 "note": "361 VALU instr per photon-step (PMC SQ_INSTS_VALU, profiles/r01d_pmc_sq.csv); writes the %.1f GB deposit log%s"
+                         % (rec * rb / 1e9, shared),
                  "photon_steps_per_sec": steps_one_launch / (w * 1e-3)},
                 {"kernel": "k_log_part", "ms": p_, "bound": "hbm", "achieved": 2 * rb * rec / (p_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "frac": 2 * rb * rec / (p_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "note": "algorithmic: every record read once and written once"},
+                 "note": "algorithmic: every record read once and written once" + shared},
                 {"kernel": "k_log_reduce", "ms": r_, "bound": "hbm", "achieved": rb * rec / (r_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "frac": rb * rec / (r_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "note": "algorithmic: every record read once"}]
+                 "note": "algorithmic: every record read once" + shared}]
             out["roofline"]["deposit_records_per_launch"] = rec
+        if alone:
+            alone["note"] = ("one job alone on the device (default launch geometry, 4 waves/SIMD), 2 launches after the timed "
+                             "region: single-job latency and kernel durations nothing overlaps")
+            if "partition_ms" in alone and stages:
+                alone["k_log_part_frac"] = 2 * rb * rec / (alone["partition_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                alone["k_log_reduce_frac"] = rb * rec / (alone["reduce_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["one_job_alone"] = alone
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblt_hip.so")
+LIB_PATH = os.environ.get("LT_HIP_LIBRARY") or os.path.join(_HERE, "liblt_hip.so")   # override: A/B builds of the same ABI
 
 TALLY = {"f32": 0, "f64": 1, "u64fx": 2}
 TALLY_NP = {0: np.float32, 1: np.float64, 2: np.uint64}

@@ -33,6 +33,18 @@ __device__ __forceinline__ unsigned tile_of(unsigned idx) { return idx >> kTileS
 // which bounds both the load imbalance and the same-address serialisation of the LDS adds on hot voxels
 constexpr uint32_t kReduceSlice = 131072;
 
+// Partition work item = kPartThreads lanes x kPerThread records held in registers.  16 records per lane (one log
+// chunk per item, 114 VGPRs) gives the longest per-tile runs; 8 per lane (64 VGPRs) lets a partition workgroup sit
+// beside three walk waves per SIMD when two jobs are in flight on the device (bench.py --inflight 2).
+#ifndef LT_PART_PER_THREAD
+#define LT_PART_PER_THREAD 16
+#endif
+constexpr int kPartThreads = 512;
+constexpr int kPerThread = LT_PART_PER_THREAD;
+constexpr uint32_t kPartItem = kPartThreads * kPerThread;       // records per work item
+constexpr uint32_t kItemsPerChunk = kLogChunk / kPartItem;
+static_assert(kLogChunk % kPartItem == 0, "a log chunk must be a whole number of partition items");
+
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_log_hist(const uint32_t* __restrict__ log_idx, const uint32_t* __restrict__ fill,
                                                   uint32_t n_chunks, uint32_t* __restrict__ hist, uint32_t n_tiles)
@@ -103,7 +115,7 @@ __global__ void __launch_bounds__(kScanThreads) k_log_scan(const uint32_t* hist,
         const uint32_t a0 = b << bits2, a1 = ((b + 1) << bits2) < n_tiles ? ((b + 1) << bits2) : n_tiles;
         const uint32_t lo = tile_base[a0], hi = a1 < n_tiles ? tile_base[a1] : s_tot[0];
         cursor1[b] = lo;
-        it = (hi - lo + kLogChunk - 1) / kLogChunk;
+        it = (hi - lo + kPartItem - 1) / kPartItem;
         items2[b] = it;   // counts for now; prefixed below
     }
     __threadfence();
@@ -118,8 +130,6 @@ __global__ void __launch_bounds__(kScanThreads) k_log_scan(const uint32_t* hist,
 // ---------------------------------------------------------------------------------------------------------
 // Partition work item: <= 4096 records.  Registers hold the item (16 records per lane), LDS holds the histogram
 // and the digit-sorted copy; each digit's run leaves as one contiguous, coalesced write.
-constexpr int kPartThreads = 512;
-constexpr int kPerThread = kLogChunk / kPartThreads;  // 16
 constexpr int kMaxBins = 1024;
 
 template <typename TV, int PASS>
@@ -129,12 +139,12 @@ __global__ void __launch_bounds__(kPartThreads) k_log_part(LogReduceParams L)
     __shared__ uint32_t s_range[3], s_next;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // digit-sorted copy of the item (96 KiB at 12 B)
     TV* s_val = reinterpret_cast<TV*>(s_dyn);
-    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_dyn + (size_t)kLogChunk * sizeof(TV));
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_dyn + (size_t)kPartItem * sizeof(TV));
 
     // Persistent workgroups pull work items from a device counter; the item count lives in device memory too
     // (chunks the walk claimed / items the scan derived), so the host never has to read anything back.
     uint32_t n_items = PASS == 1 ? L.chunks_used[0] : L.totals[1];
-    if (PASS == 1 && n_items > L.cap_chunks) n_items = L.cap_chunks;
+    if (PASS == 1) n_items = (n_items > L.cap_chunks ? L.cap_chunks : n_items) * kItemsPerChunk;
   for (;;) {
     if (threadIdx.x == 0) s_next = atomicAdd(&L.work[PASS - 1], 1u);
     __syncthreads();
@@ -147,7 +157,8 @@ __global__ void __launch_bounds__(kPartThreads) k_log_part(LogReduceParams L)
     if (PASS == 1) {
         in_idx = L.log_idx; in_val = reinterpret_cast<const TV*>(L.log_val);
         out_idx = L.tmp_idx; out_val = reinterpret_cast<TV*>(L.tmp_val);
-        lo = item * kLogChunk; n = L.log_fill[item];
+        const uint32_t fill = L.log_fill[item / kItemsPerChunk], part = (item % kItemsPerChunk) * kPartItem;
+        lo = item * kPartItem; n = fill > part ? (fill - part < kPartItem ? fill - part : kPartItem) : 0;
         cursor = L.cursor1; nb = nb1;
     } else {
         in_idx = L.tmp_idx; in_val = reinterpret_cast<const TV*>(L.tmp_val);
@@ -156,8 +167,8 @@ __global__ void __launch_bounds__(kPartThreads) k_log_part(LogReduceParams L)
             uint32_t a = 0, b = nb1;
             while (b - a > 1) { uint32_t m = (a + b) >> 1; if (L.items2[m] <= item) a = m; else b = m; }
             const uint32_t t0 = a << L.bits2, t1 = ((a + 1) << L.bits2) < L.n_tiles ? ((a + 1) << L.bits2) : L.n_tiles;
-            const uint32_t rlo = L.tile_base[t0] + (item - L.items2[a]) * kLogChunk, rhi = L.tile_base[t1];
-            s_range[0] = rlo; s_range[1] = rhi - rlo < kLogChunk ? rhi - rlo : kLogChunk; s_range[2] = a;
+            const uint32_t rlo = L.tile_base[t0] + (item - L.items2[a]) * kPartItem, rhi = L.tile_base[t1];
+            s_range[0] = rlo; s_range[1] = rhi - rlo < kPartItem ? rhi - rlo : kPartItem; s_range[2] = a;
         }
         __syncthreads();
         lo = s_range[0]; n = s_range[1];
@@ -302,7 +313,7 @@ static unsigned persistent_blocks(const void* fn, int threads, size_t lds)
 
 template <typename TV, int PASS> static hipError_t launch_part_t(const LogReduceParams& L, hipStream_t s)
 {
-    const size_t lds = (size_t)kLogChunk * (sizeof(TV) + sizeof(uint32_t));
+    const size_t lds = (size_t)kPartItem * (sizeof(TV) + sizeof(uint32_t));
     const void* fn = reinterpret_cast<const void*>(&k_log_part<TV, PASS>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

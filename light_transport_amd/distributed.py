@@ -55,7 +55,8 @@ def reduce_device(ctx, group=None, dst=None):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         else:
             dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    torch.cuda.synchronize(ctx.device_id)
+    # wait for the collective only (torch's stream), not for other contexts' streams that may have jobs in flight
+    torch.cuda.current_stream(ctx.device_id).synchronize()
 
 
 def reduce_host(grid, counters, group=None, dst=None):
