@@ -586,3 +586,31 @@ def test_log_tally_equals_atomic_tally(ctx):
             tol = 1e-11 if dtype == "f64" else 2e-3   # f32 sums of ~1e-2 deposits onto ~2e3: order matters at 1e-3
             assert np.abs(a - b).max() <= tol * a.max()
     ctx.set_tally_mode("auto", 0)
+
+
+# ---------------------------------------------------------------- several jobs in flight on one GPU
+def test_job_pipeline_matches_single_context(ctx):
+    """Two contexts taking jobs in turn (light_transport_amd.JobPipeline, what bench.py --inflight 2 does) return, in
+    order, exactly the fixed-point grids and counters one context produces job by job -- and the oracle's for job 0."""
+    from light_transport_amd import JobPipeline
+    prob = S.two_layer(n=32)
+    jobs = [dict(n_photons=3000 + 500 * k, seed=40 + k, photon_offset=1000 * k, tag=k) for k in range(5)]
+
+    def configure(c):
+        prob.apply(c, "u64fx")
+        c.set_tally_mode(1)            # log tally: walk + partition + reduce per job, the kernels that overlap
+
+    pipe = JobPipeline(configure, depth=2, raw=True)
+    got = list(pipe.run(jobs))
+    pipe.close()
+    assert [t for t, _, _ in got] == [0, 1, 2, 3, 4]
+    configure(ctx)
+    for (tag, grid, cnt), j in zip(got, jobs):
+        ctx.zero_tally(); ctx.launch(j["n_photons"], seed=j["seed"], photon_offset=j["photon_offset"]); ctx.sync()
+        assert np.array_equal(grid, ctx.read_grid_raw()), "job %d differs from the single-context run" % tag
+        c1 = ctx.read_counters()
+        assert cnt["steps"] == c1["steps"] and cnt["photons"] == j["n_photons"]
+        assert abs(cnt["w_absorbed"] - c1["w_absorbed"]) < 1e-9 * j["n_photons"]
+    ctx.set_tally_mode(2)
+    _, fxo, co = prob.oracle().run(jobs[0]["n_photons"], seed=jobs[0]["seed"], threads=8, want_fx=True, want_f64=False)
+    assert np.array_equal(got[0][1], fxo) and got[0][2]["steps"] == co["steps"]

@@ -189,3 +189,44 @@ def test_obj_loader_on_reference_assets():
     assert len(v) == 4583 and len(f) == 5804
     v, f = read_obj(d + "pumpkin.obj")
     assert len(v) == 5002 and len(f) == 10000
+
+
+def test_job_pipeline_scheduling(monkeypatch):
+    """JobPipeline hands jobs to its contexts in turn, completes the oldest job before re-using its context and
+    returns results in submission order (logic only: a recording stand-in replaces the device context)."""
+    from light_transport_amd import pipeline as PL
+    log = []
+
+    class FakeCtx:
+        n = 0
+
+        def __init__(self, device_id):
+            self.id = FakeCtx.n; FakeCtx.n += 1; self.job = None
+        def set_launch_config(self, b, t): log.append(("cfg", self.id, b, t))
+        def zero_tally(self): log.append(("zero", self.id))
+        def launch(self, n, seed=0, photon_offset=0, f32_walk=False): self.job = (n, seed, photon_offset); log.append(("launch", self.id, seed))
+        def sync(self): log.append(("sync", self.id))
+        def read_grid(self): return ("grid", self.job)
+        def read_grid_raw(self): return ("raw", self.job)
+        def read_counters(self): return {"photons": self.job[0]}
+        def close(self): log.append(("close", self.id))
+
+    monkeypatch.setattr(PL._lib, "Context", FakeCtx)
+    configured = []
+    pipe = PL.JobPipeline(lambda c: configured.append(c.id), depth=2)
+    assert configured == [0, 1] and [e for e in log if e[0] == "cfg"] == [("cfg", 0, 2, 256), ("cfg", 1, 2, 256)]
+    out = list(pipe.run(dict(n_photons=100 + k, seed=k, tag="job%d" % k) for k in range(5)))
+    assert [t for t, _, _ in out] == ["job%d" % k for k in range(5)]
+    assert [g[1][1] for _, g, _ in out] == [0, 1, 2, 3, 4] and [c["photons"] for _, _, c in out] == [100, 101, 102, 103, 104]
+    launches = [e for e in log if e[0] in ("launch", "sync")]
+    # contexts alternate; job k-2 is synced right before job k is launched on the same context
+    assert launches[:4] == [("launch", 0, 0), ("launch", 1, 1), ("sync", 0), ("launch", 0, 2)]
+    assert [e[1] for e in log if e[0] == "launch"] == [0, 1, 0, 1, 0]
+    assert pipe.submit(10, seed=9, tag="x") is None and pipe.submit(11, seed=10, tag="y") is None   # both contexts free
+    assert [t for t, _, _ in pipe.drain()] == ["x", "y"]
+    pipe.close()
+    with pytest.raises(ValueError):
+        PL.JobPipeline(lambda c: None, depth=0)
+    one = PL.JobPipeline(lambda c: None, depth=1, raw=True)     # depth 1: strictly one job at a time, no launch cap
+    assert not [e for e in log if e[0] == "cfg" and e[1] == one.ctxs[0].id]
+    assert one.submit(5, tag="a") is None and one.submit(6, tag="b")[0] == "a" and one.drain()[0][1][0] == "raw"
