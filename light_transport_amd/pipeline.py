@@ -70,6 +70,40 @@ class JobPipeline:
         for done in self.drain():
             yield done
 
+    def trace(self, n_photons, seed=0, photon_offset=0, batch=None, f32_walk=False):
+        """ONE large job spread over the contexts: ids [photon_offset, photon_offset + n_photons) are cut into batches
+        of ``batch`` photons (default: n / (4 * depth)) that the contexts take in turn, each ACCUMULATING into its own
+        grid, so that one batch's log reduction runs beside the next batch's walk.  Returns (grid, counters) summed
+        over the contexts -- identical to a single launch for the integer tally and the counters' integer fields,
+        equal up to summation order otherwise.  The overlap pays for grids of up to ~2000 tiles (256^3: 1024); at
+        512^3 the walk's per-workgroup tile histogram (64 KiB of LDS) leaves no room for a partition workgroup beside
+        it and the time equals a single launch's (tools/big_job.py: 0.67 s either way for config 5's 10^8 photons)."""
+        if self._pending:
+            raise RuntimeError("trace() needs an idle pipeline: drain() first")
+        n_photons = int(n_photons)
+        if batch is None:
+            batch = max(1, -(-n_photons // (4 * len(self.ctxs))))
+        for c in self.ctxs:
+            c.zero_tally()
+        done, k = 0, 0
+        while done < n_photons:
+            b = min(int(batch), n_photons - done)
+            self.ctxs[k % len(self.ctxs)].launch(b, seed=seed, photon_offset=photon_offset + done, f32_walk=f32_walk)
+            done += b
+            k += 1
+        grid, counters = None, None
+        for c in self.ctxs:
+            c.sync()
+            g = c.read_grid_raw() if self.raw else c.read_grid()
+            cn = c.read_counters()
+            if grid is None:
+                grid, counters = g, dict(cn)
+            else:
+                grid += g
+                for key, v in cn.items():
+                    counters[key] += v
+        return grid, counters
+
     def close(self):
         for c in self.ctxs:
             c.close()

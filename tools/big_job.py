@@ -20,3 +20,26 @@ for mode in ("log", "atomic"):
            + c["w_roulette_net"] + c["w_capped"])
     print("   conservation residual / N = %.3e" % ((tot - n) / n), flush=True)
 print("log == atomic (bit for bit):", np.array_equal(res["log"], res["atomic"]))
+
+# the same job through two contexts taking its batches in turn (JobPipeline.trace)
+del ctx
+def configure(c):
+    prob.apply(c, "u64fx"); c.set_tally_mode("log")
+pipe = lt.JobPipeline(configure, depth=2, raw=True)
+def timed(batch):
+    for c in pipe.ctxs: c.zero_tally(); c.sync()
+    t0 = time.time(); done = k = 0
+    while done < n:
+        b = min(batch, n - done); pipe.ctxs[k % 2].launch(b, seed=11, photon_offset=done); done += b; k += 1
+    for c in pipe.ctxs: c.sync()
+    return time.time() - t0
+timed(10 ** 7)                                               # warm-up: sizes the logs
+for batch in (10 ** 7, 5 * 10 ** 6, 2500000):
+    dt = timed(batch)
+    steps = sum(c.read_counters()["steps"] for c in pipe.ctxs)
+    g = pipe.ctxs[0].read_grid_raw() + pipe.ctxs[1].read_grid_raw()
+    print("two contexts, batches of %.1e: %.3f s to the last sync, %.2f Gsteps/s, steps %d, == single launch: %s" % (
+        batch, dt, steps / dt / 1e9, steps, np.array_equal(g, res["log"])), flush=True)
+g, c = pipe.trace(n, seed=11, batch=5 * 10 ** 6)
+print("JobPipeline.trace: steps %d, == single launch: %s" % (c["steps"], np.array_equal(g, res["log"])))
+pipe.close()
