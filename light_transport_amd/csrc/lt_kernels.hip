@@ -91,6 +91,14 @@ LT_DEV double sqrt01(double x)                           // x in [0, 1]; 0 (and 
     return sqrt_core(xc, __builtin_amdgcn_rsq(__builtin_fmax(xc, 1e-300)));
 }
 LT_DEV double sqrt_pos(double x) { return sqrt_core(x, __builtin_amdgcn_rsq(x)); }   // x > 0 known
+LT_DEV double rsqrt_pos(double x)                        // 1 / sqrt(x), x > 0 well scaled: v_rsq_f64 + 2 Newton steps
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-(x * y), y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    e = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(0.5 * y, e, y);
+}
 LT_DEV double neg_log_unit(double x)                     // -ln(x), x in [2^-53, 1]
 {
     int e = __builtin_amdgcn_frexp_exp(x);
@@ -150,6 +158,7 @@ template <> struct Mx<double> {
     static LT_DEV double neg_log(double xi) { return neg_log_unit(xi); }
     static LT_DEV double sqrt_unit(double x) { return sqrt01(x); }
     static LT_DEV double sqrt_pos(double x) { return ltk::sqrt_pos(x); }
+    static LT_DEV double rsqrt_pos(double x) { return ltk::rsqrt_pos(x); }
     static LT_DEV double quot(double a, double b) { return fast_div(a, b); }
     static LT_DEV void sincos_turn(double xi, double* s, double* c) { sincos_turn_f64(xi, s, c); }
     static LT_DEV double inf() { return __builtin_huge_val(); }
@@ -173,6 +182,7 @@ template <> struct Mx<float> {
     static LT_DEV float neg_log(float xi) { return -::logf(xi); }
     static LT_DEV float sqrt_unit(float x) { return ::sqrtf(__builtin_fmaxf(x, 0.0f)); }
     static LT_DEV float sqrt_pos(float x) { return ::sqrtf(x); }
+    static LT_DEV float rsqrt_pos(float x) { return 1.0f / ::sqrtf(x); }
     static LT_DEV float quot(float a, float b) { return a / b; }
     static LT_DEV void sincos_turn(float xi, float* s, float* c) { ::sincospif(2.0f * xi, s, c); }
     static LT_DEV float inf() { return __builtin_huge_valf(); }
@@ -405,10 +415,10 @@ template <typename R> LT_DEV void spin(R* u, R ct, R xi_phi)
     if (Mx<R>::abs(uz) > (R)0.99999) {
         u[0] = st * cp; u[1] = st * sp; u[2] = uz >= 0 ? ct : -ct;
     } else {
-        R t2 = (R)1 - uz * uz;
-        R tmp = Mx<R>::sqrt_pos(t2);                    // |uz| <= 0.99999: t2 >= 2e-5
-        u[0] = Mx<R>::quot(st * (ux * uz * cp - uy * sp), tmp) + ux * ct;
-        u[1] = Mx<R>::quot(st * (uy * uz * cp + ux * sp), tmp) + uy * ct;
+        R t2 = (R)1 - uz * uz;                          // |uz| <= 0.99999: t2 >= 2e-5
+        R inv = Mx<R>::rsqrt_pos(t2), tmp = t2 * inv;   // 1 / sqrt(t2) once; the two quotients become products
+        u[0] = st * (ux * uz * cp - uy * sp) * inv + ux * ct;
+        u[1] = st * (uy * uz * cp + ux * sp) * inv + uy * ct;
         u[2] = -st * cp * tmp + uz * ct;
     }
 }
