@@ -3,8 +3,8 @@
 A ``Context`` is one HIP stream with its own voxel grid and deposit log, and ``launch`` is asynchronous.  The walk is
 compute-bound, the log reduction that follows it is bandwidth-bound; driven one job at a time they run back to back.
 ``JobPipeline`` keeps ``depth`` identically configured contexts and hands consecutive jobs to them in turn, with the walk
-limited to 2 workgroups per CU per job, so that one job's reduction runs beside the next job's walk (C2 on MI355X: 38.7 ms
-per job instead of 46.1).  Results come back in submission order and are the same numbers a single
+limited to 2 workgroups per CU per job, so that one job's reduction runs beside the next job's walk (C2 on MI355X: 37.5 ms
+per job instead of 45.5).  Results come back in submission order and are the same numbers a single
 context produces: a photon's trajectory depends on (seed, photon id) only.
 
 The reference's counterpart is Numba's thread pool working through the pixels of one render_scene call
