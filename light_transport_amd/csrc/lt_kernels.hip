@@ -380,6 +380,15 @@ template <typename R> LT_DEV void reflect(const R* v, const R* n, R* o)
     normalize3(o);
 }
 
+// the walk's form: same expression, normalised with one reciprocal square root (|o| = 1 to rounding already)
+template <typename R> LT_DEV void reflect_walk(const R* v, const R* n, R* o)
+{
+    R k = (R)2 * dot3(v, n);
+    o[0] = v[0] - k * n[0]; o[1] = v[1] - k * n[1]; o[2] = v[2] - k * n[2];
+    const R inv = Mx<R>::rsqrt_pos(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+    o[0] *= inv; o[1] *= inv; o[2] *= inv;
+}
+
 // Dielectric boundary (App. C.5): exact unpolarised Fresnel + the refraction
 // vector of S/path_tracing_fix1.py:107-114 with Nr = n1/n2; TIR when the
 // radicand <= 0 (:110).  nf faces the incoming photon.
@@ -390,17 +399,20 @@ template <typename R> LT_DEV R boundary(const R* d, const R* nf, R n1, R n2, R* 
         *cos_t_out = cos_i; refr[0] = d[0]; refr[1] = d[1]; refr[2] = d[2];
         return 0;
     }
-    R Nr = n1 / n2;
+    // lean arithmetic (Mx::quot / sqrt_pos / rsqrt_pos: v_rcp / v_rsq + Newton, <= 1-2 ulp): this block runs whenever
+    // ANY lane of the wave sits on an interface, which in a layered medium is most wave-steps
+    R Nr = Mx<R>::quot(n1, n2);
     R rad = (R)1 - Nr * Nr * ((R)1 - cos_i * cos_i);
     if (rad <= 0) { *cos_t_out = 0; refr[0] = refr[1] = refr[2] = 0; return 1; }
-    R cos_t = Mx<R>::sqrt(rad);
+    R cos_t = Mx<R>::sqrt_pos(rad);
     R a = n1 * cos_i, b = n2 * cos_t, c = n1 * cos_t, e = n2 * cos_i;
-    R rs = (a - b) / (a + b), rp = (c - e) / (c + e);
+    R rs = Mx<R>::quot(a - b, a + b), rp = Mx<R>::quot(c - e, c + e);
     R k = Nr * cos_i - cos_t;
     refr[0] = d[0] * Nr + nf[0] * k;
     refr[1] = d[1] * Nr + nf[1] * k;
     refr[2] = d[2] * Nr + nf[2] * k;
-    normalize3(refr);
+    const R inv = Mx<R>::rsqrt_pos(refr[0] * refr[0] + refr[1] * refr[1] + refr[2] * refr[2]);   // normalize, S/vectors.py:6-7
+    refr[0] *= inv; refr[1] *= inv; refr[2] *= inv;
     *cos_t_out = cos_t;
     return (R)0.5 * (rs * rs + rp * rp);
 }
@@ -824,7 +836,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (GEOM == 0 ? LT_F64_SLA
                         record_vertex<R>(P, pid - P.photon_offset, nv, px, py, pz, ux, uy, uz, w,
                                          (u4[3] <= Rf) ? LT_VERTEX_REFLECTIVE : LT_VERTEX_TRANSMISSIVE, cur, step);
                     if (u4[3] <= Rf) {  // reflect: S/brdf.py:8-9
-                        R ro[3]; reflect(d, nf, ro);
+                        R ro[3]; reflect_walk(d, nf, ro);
                         ux = ro[0]; uy = ro[1]; uz = ro[2];
                         if constexpr (MESH) { px += eps * nf[0]; py += eps * nf[1]; pz += eps * nf[2]; }  // :118
                     } else {
