@@ -580,7 +580,7 @@ constexpr unsigned kPacket = 64;  // photon ids taken from the global queue per 
 // minimum waves per SIMD the register allocator must leave room for (occupancy is what hides the latency of the
 // dependent f64 / transcendental chains once deposition no longer paces the walk)
 #ifndef LT_F64_WAVES
-#define LT_F64_WAVES 3        // f64 mesh walks: 4 would spill ~80 B per lane
+#define LT_F64_WAVES 4        // f64 mesh walks: ~80 B of scratch per lane at 128 VGPRs, still 6 % faster than 3 waves (C4)
 #endif
 #ifndef LT_F64_SLAB_WAVES
 #define LT_F64_SLAB_WAVES 4   // f64 slab walks fit 128 VGPRs without scratch since the polynomial constants live in SGPRs
@@ -754,6 +754,17 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (GEOM == 0 ? LT_F64_SLA
             } else {
                 step++;
                 acc_steps++;
+                // mesh walks: the clearance of the current cell is a dependent global load; requested here, before the
+                // ~150 instructions of RNG and logarithm, its latency is hidden by the time the hop length is known
+                float clr = -1.0f;   // no grid / outside it: always query
+                if constexpr (MESH) {
+                    if (P.clear) {
+                        const R cx = (px - (R)P.corg[0]) * (R)P.cinv[0], cy = (py - (R)P.corg[1]) * (R)P.cinv[1],
+                                cz = (pz - (R)P.corg[2]) * (R)P.cinv[2];
+                        if (cx >= 0 && cx < (R)P.cnx && cy >= 0 && cy < (R)P.cny && cz >= 0 && cz < (R)P.cnz)
+                            clr = P.clear[((size_t)(int)cz * P.cny + (int)cy) * P.cnx + (int)cx];
+                    }
+                }
                 R u4[4];
                 if constexpr (TABLE) {  // table RNG: S/scene.py:68-69, S/path_tracing_fix1.py:28-29
                     const double* t = P.table + ((pid - P.photon_offset) * P.table_steps + grp) * 4;
@@ -789,15 +800,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (GEOM == 0 ? LT_F64_SLA
                 } else {
                     // clearance grid: every triangle is farther than `c` from every point of this cell, so a hop of
                     // length s < c ends before any surface and the traversal is skipped (same result, no query)
-                    bool query = true;
-                    if (P.clear) {
-                        const R cx = (px - (R)P.corg[0]) * (R)P.cinv[0], cy = (py - (R)P.corg[1]) * (R)P.cinv[1],
-                                cz = (pz - (R)P.corg[2]) * (R)P.cinv[2];
-                        if (cx >= 0 && cx < (R)P.cnx && cy >= 0 && cy < (R)P.cny && cz >= 0 && cz < (R)P.cnz) {
-                            const float c = P.clear[((size_t)(int)cz * P.cny + (int)cy) * P.cnx + (int)cx];
-                            query = !(s < (R)c);
-                        }
-                    }
+                    const bool query = !(s < (R)clr);
                     if (query) {
                         R o[3] = {px, py, pz}, d[3] = {ux, uy, uz}, th;
                         nearest_bvh(s_tris, s_nodes, P.n_nodes, o, d, s, hit_tri, th);
