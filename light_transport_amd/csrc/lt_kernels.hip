@@ -446,6 +446,19 @@ LT_DEV unsigned long long mix_seed(unsigned long long seed, unsigned long long p
     return z ^ (z >> 31);
 }
 
+// One stream per photon.  rocrand_init from a seed alone leaves three of the five XORWOW state words offset by the
+// same 32-bit value, and every photon's first draws (first step length, first deflection) inherit that structure:
+// at 10^8 photons the matched-slab benchmark sat 9e-5 (10 sigma) off van de Hulst's Rd / Tt, with a seed-to-seed
+// scatter well below the statistical one.  Discarding kRngWarmup outputs after seeding removes both (4 ... 32
+// discards agree to 1e-5; profiles/r01e_rng_seeding.log).  56 instructions per photon against ~10^5 for its walk.
+constexpr int kRngWarmup = 8;
+LT_DEV void photon_stream(unsigned long long seed, unsigned long long photon_id, rocrand_state_xorwow* st)
+{
+    rocrand_init(mix_seed(seed, photon_id), 0ull, 0ull, st);
+#pragma unroll
+    for (int k = 0; k < kRngWarmup; k++) (void)rocrand(st);
+}
+
 // ---------------------------------------------------------------------------
 // tally
 // ---------------------------------------------------------------------------
@@ -687,7 +700,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (GEOM == 0 ? LT_F64_SLA
                 pid = P.photon_offset + id;
                 alive = true; w = 1; sleft = 0; step = 0; grp = 0;
                 max_steps = P.max_steps;
-                if constexpr (!TABLE) rocrand_init(mix_seed(P.seed, pid), 0ull, 0ull, &rng);
+                if constexpr (!TABLE) photon_stream(P.seed, pid, &rng);
                 if (P.src_type == LT_SRC_COSINE_QUAD) {
                     R u4[4];
                     if constexpr (TABLE) {
@@ -1082,7 +1095,7 @@ __global__ void k_rng_raw(unsigned long long seed, unsigned long long photon_id,
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     rocrand_state_xorwow st;
-    rocrand_init(mix_seed(seed, photon_id), 0ull, 0ull, &st);
+    photon_stream(seed, photon_id, &st);
     for (unsigned i = 0; i < count; i++) out[i] = rocrand(&st);
 }
 
