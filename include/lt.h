@@ -44,7 +44,11 @@ extern "C" {
 #define LT_TALLY_F32 0   /* global_atomic_add_f32                         */
 #define LT_TALLY_F64 1   /* global_atomic_add_f64                         */
 #define LT_TALLY_U64FX 2 /* u64 fixed point, 2^40 units per unit weight:
-                            order-independent, bit-reproducible           */
+                            order-independent, bit-reproducible.  One voxel
+                            holds at most 2^24 = 1.68e7 units of weight
+                            before it wraps (C2's hottest voxel absorbs
+                            0.0074 per photon: ~2e9 photons per grid);
+                            read the grid out and zero it before that      */
 #define LT_FX_SCALE 1099511627776.0 /* 2^40 */
 
 /* photon sources (lt_set_source) */
