@@ -586,6 +586,10 @@ LT_DEV void emit_deposit(const WalkParams& P, bool has, unsigned idx, typename T
 }
 
 constexpr unsigned kPacket = 64;  // photon ids taken from the global queue per atomic
+#ifndef LT_REFILL_MIN
+#define LT_REFILL_MIN 4
+#endif
+constexpr unsigned kRefillMin = LT_REFILL_MIN;   // dead lanes a wave collects before it refills them
 
 // ---------------------------------------------------------------------------
 // the walk kernel
@@ -664,8 +668,13 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (GEOM == 0 ? LT_F64_SLA
 
     for (;;) {
         // ---------------- refill dead lanes (ballot + rank) ----------------
+        // Refilling costs the whole wave ~140 instructions (seeding + stream warm-up + emission) however few lanes
+        // take part, and some lane dies in one wave-step out of five: waiting until kRefillMin lanes are free cuts that
+        // overhead fourfold for an average of 1.5 idle lanes.  A photon's fate depends on (seed, id) only, so the
+        // results do not change.
         unsigned long long need = __ballot(!alive);
-        if (need != 0ull && !(q_done && pk_next >= pk_end)) {
+        if (need != 0ull && !(q_done && pk_next >= pk_end) &&
+            ((unsigned)__popcll(need) >= kRefillMin || need == __ballot(true))) {
             const unsigned cnt = (unsigned)__popcll(need);
             const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32),
                                       __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
