@@ -266,7 +266,7 @@ def main():
             shared = " (shares the device with the other job in flight: durations overlap)" if depth > 1 else ""
             out["roofline"]["kernels"] = [
                 {"kernel": "walk_kernel", "ms": w, "bound": "valu",
-                 "note": "351 VALU instr per photon-step (PMC SQ_INSTS_VALU, profiles/r01e_pmc_sq.csv); writes the %.1f GB deposit log%s"
+                 "note": "349 VALU instr per photon-step (PMC SQ_INSTS_VALU, profiles/r01e_pmc_sq.csv); writes the %.1f GB deposit log%s"
                          % (rec * rb / 1e9, shared),
                  "photon_steps_per_sec": steps_one_launch / (w * 1e-3)},
                 {"kernel": "k_log_part", "ms": p_, "bound": "hbm", "achieved": 2 * rb * rec / (p_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
