@@ -233,7 +233,13 @@ int upload_tables(lt_ctx* c)
             double ext[3], longest = 0;
             for (int k = 0; k < 3; k++) { ext[k] = c->nodes[0].hi[k] - c->nodes[0].lo[k]; if (ext[k] > longest) longest = ext[k]; }
             if (longest > 0 && std::isfinite(longest)) {
-                const double h = longest / 64.0;
+                // cells along the longest axis: as fine as a brute-force build (cells x triangles distance evaluations)
+                // of ~2e9 evaluations allows, between 32 and 128 (C4's 30 triangles: 128, 8 MiB; a 5000-triangle mesh: 73)
+                int per_axis = (int)std::cbrt(2.0e9 / (double)(t64.empty() ? 1 : t64.size()));
+                per_axis = per_axis < 32 ? 32 : (per_axis > 128 ? 128 : per_axis);
+                // LT_CLEARANCE_CELLS overrides (tuning experiments)
+                if (const char* e = std::getenv("LT_CLEARANCE_CELLS")) { int v = std::atoi(e); if (v >= 8 && v <= 512) per_axis = v; }
+                const double h = longest / (double)per_axis;
                 for (int k = 0; k < 3; k++) {
                     c->cn[k] = (int)std::ceil(ext[k] / h); if (c->cn[k] < 1) c->cn[k] = 1;
                     c->ccell[k] = ext[k] > 0 ? ext[k] / c->cn[k] : h; c->corg[k] = c->nodes[0].lo[k];
