@@ -25,8 +25,9 @@ tracer.run(n, seed=0)
 absorbed = tracer.absorbed()                                                 # [nz, ny, nx] float64
 dt = time.time() - t0
 c = tracer.counters()
-print("%d photons, %d photon-steps in %.3f s wall (%.1f ms on the device): %.1f G photon-steps/s"
-      % (n, c["steps"], dt, tracer.kernel_ms(), c["steps"] / tracer.kernel_ms() / 1e6))
+print("%d photons, %d photon-steps: %.1f ms on the device = %.1f G photon-steps/s (%.2f s wall for this first call, "
+      "which also allocates the 40 GB deposit log; later calls reuse it)"
+      % (n, c["steps"], tracer.kernel_ms(), c["steps"] / tracer.kernel_ms() / 1e6, dt))
 print("absorbed %.4f, diffuse reflectance %.4f, lost outside the grid %.2e (fractions of launched weight)"
       % (c["w_absorbed"] / n, c["w_escaped_top"] / n, c["w_lost_outside_grid"] / n))
 phi = fluence(absorbed, tissue.mu_a, grid.voxel_volume, n)
