@@ -223,7 +223,7 @@ class Context:
 
     def set_tally_mode(self, mode="auto", log_bytes=0):
         """'atomic': global atomics per deposit; 'log': deposit log + tile partition + LDS reduce;
-        'auto' (default): log for layered slabs, atomic for meshes."""
+        'auto' (default): log for layered slabs and f32 mesh walks, atomic for f64 mesh walks."""
         m = {"atomic": 0, "log": 1, "auto": 2}[mode] if isinstance(mode, str) else int(mode)
         self._ck(lib().lt_set_tally_mode(self._h, C.c_int(m), C.c_uint64(int(log_bytes))), "lt_set_tally_mode")
 

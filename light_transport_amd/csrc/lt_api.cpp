@@ -578,9 +578,9 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     const uint32_t n_tiles = ntx * nty * ntz;   // 32 x 32 x 16-voxel blocks
     const uint32_t n_tiles_pre = (uint32_t)((c->n_vox() + kTileSize - 1) >> kTileShift);
     (void)n_tiles_pre;
-    // auto: slab walks are paced by the atomic unit -> log; mesh walks are paced by BVH arithmetic, which hides the
-    // atomics, so the extra log passes would only add time (C4: 101 ms atomic vs 114 ms log)
-    const int mode = c->tally_mode == 2 ? (c->have_mesh ? 0 : 1) : c->tally_mode;
+    // auto: slab walks and f32 mesh walks are paced by the atomic unit -> log (C4, f32: 43 ms log vs 60 ms atomic);
+    // the f64 mesh walk's BVH arithmetic hides the atomics, so the log passes would only add time (58 vs 59 ms)
+    const int mode = c->tally_mode == 2 ? ((c->have_mesh && !v.f32) ? 0 : 1) : c->tally_mode;
     { int rc3 = collect_log_stats(c); if (rc3) return rc3; }   // stats of the previous launch size this one
     bool use_log = mode == 1 && !v.table && c->max_vertices == 0 && n_tiles <= 16384 && !std::getenv("LT_DIAG_NO_TALLY");
     if (use_log) {

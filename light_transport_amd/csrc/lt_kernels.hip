@@ -590,6 +590,10 @@ constexpr unsigned kPacket = 64;  // photon ids taken from the global queue per 
 #define LT_REFILL_MIN 4
 #endif
 constexpr unsigned kRefillMin = LT_REFILL_MIN;   // dead lanes a wave collects before it refills them
+#ifndef LT_QUERY_MIN
+#define LT_QUERY_MIN 16
+#endif
+constexpr unsigned kQueryMin = LT_QUERY_MIN;     // mesh walks: lanes a wave collects before it runs their BVH queries
 
 // ---------------------------------------------------------------------------
 // the walk kernel
@@ -605,338 +609,16 @@ constexpr unsigned kRefillMin = LT_REFILL_MIN;   // dead lanes a wave collects b
 #ifndef LT_F32_WAVES
 #define LT_F32_WAVES 5
 #endif
-template <typename R, int GEOM, bool TABLE, int TALLY>
-__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (GEOM == 0 ? LT_F64_SLAB_WAVES : LT_F64_WAVES) : (GEOM == 0 ? LT_F32_WAVES : 4))) walk_kernel(const WalkParams P)
-{
-    constexpr bool MESH = GEOM != 0;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    // GEOM 2: the mesh is too large for LDS -> triangles and nodes are read from global memory (they are
-    // read-only and shared by every wave, so they live in the XCD L2s / Infinity Cache after first touch)
-    const LdsLayout<R> L(P.n_media, P.n_layers, GEOM == 1 ? P.n_tris : 0, GEOM == 1 ? P.n_nodes : 0,
-                         P.log_idx ? P.log_n_tiles : 0u);
-    uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds_raw + L.off_hist);   // log mode: records per grid tile
-    if (P.log_idx) for (unsigned t = threadIdx.x; t < P.log_n_tiles; t += blockDim.x) s_hist[t] = 0;
-    double* s_cnt = reinterpret_cast<double*>(lds_raw + L.off_cnt);
-    const MedD<R>* s_med = reinterpret_cast<const MedD<R>*>(lds_raw + L.off_media);
-    const R* s_zb = reinterpret_cast<const R*>(lds_raw + L.off_zb);
-    const int32_t* s_lm = reinterpret_cast<const int32_t*>(lds_raw + L.off_lm);
-    const TriD<R>* s_tris = GEOM == 2 ? reinterpret_cast<const TriD<R>*>(P.tris)
-                                      : reinterpret_cast<const TriD<R>*>(lds_raw + L.off_tris);
-    const NodeD<R>* s_nodes = GEOM == 2 ? reinterpret_cast<const NodeD<R>*>(P.nodes)
-                                        : reinterpret_cast<const NodeD<R>*>(lds_raw + L.off_nodes);
-
-    if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0.0;
-    lds_copy(lds_raw + L.off_media, P.media, (size_t)P.n_media * sizeof(MedD<R>));
-    if constexpr (!MESH) {
-        lds_copy(lds_raw + L.off_zb, P.zb, (size_t)(P.n_layers + 1) * sizeof(R));
-        lds_copy(lds_raw + L.off_lm, P.layer_medium, (size_t)P.n_layers * sizeof(int32_t));
-    } else if constexpr (GEOM == 1) {
-        lds_copy(lds_raw + L.off_tris, P.tris, (size_t)P.n_tris * sizeof(TriD<R>));
-        lds_copy(lds_raw + L.off_nodes, P.nodes, (size_t)P.n_nodes * sizeof(NodeD<R>));
-    }
-    __syncthreads();
-
-    const R eps = (R)1e-6;  // EPSILON, S/constants.py:12
-    const R inf = Mx<R>::inf();
-    const int lane = threadIdx.x & 63;
-
-    // per-lane photon state
-    bool alive = false;
-    R px = 0, py = 0, pz = 0, ux = 0, uy = 0, uz = 1, w = 0, sleft = 0;
-    int cur = 0;
-    unsigned step = 0, max_steps = P.max_steps, nv = 0;
-    unsigned long long pid = 0, grp = 0;
-    rocrand_state_xorwow rng;
-    // per-lane accumulators of the frequent events
-    double acc_abs = 0.0, acc_lost = 0.0;
-    unsigned long long acc_steps = 0;
-    // run-length accumulation: consecutive deposits into the same voxel (a third of all steps when the
-    // voxel is one mean free path wide) are summed in registers and sent as ONE atomic request
-    typedef typename TallyT<TALLY>::type TV;
-    constexpr unsigned kNoVoxel = 0xffffffffu;
-    unsigned pend_idx = kNoVoxel;
-    TV pend_val = 0;
-    // wave-level deposit-log cursor (log mode): records [lg_cur, lg_end) of chunk lg_chunk are free
-    unsigned lg_cur = 0, lg_end = 0, lg_chunk = kNoVoxel;
-    // wave-level packet of photon ids [pk_next, pk_end)
-    unsigned long long pk_next = 0, pk_end = 0;
-    bool q_done = false;
-
-    const R gx0 = (R)P.origin[0], gy0 = (R)P.origin[1], gz0 = (R)P.origin[2];
-    const R ivx = (R)P.inv_voxel[0], ivy = (R)P.inv_voxel[1], ivz = (R)P.inv_voxel[2];
-    const R fnx = (R)P.nx, fny = (R)P.ny, fnz = (R)P.nz;
-
-    for (;;) {
-        // ---------------- refill dead lanes (ballot + rank) ----------------
-        // Refilling costs the whole wave ~140 instructions (seeding + stream warm-up + emission) however few lanes
-        // take part, and some lane dies in one wave-step out of five: waiting until kRefillMin lanes are free cuts that
-        // overhead fourfold for an average of 1.5 idle lanes.  A photon's fate depends on (seed, id) only, so the
-        // results do not change.
-        unsigned long long need = __ballot(!alive);
-        if (need != 0ull && !(q_done && pk_next >= pk_end) &&
-            ((unsigned)__popcll(need) >= kRefillMin || need == __ballot(true))) {
-            const unsigned cnt = (unsigned)__popcll(need);
-            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32),
-                                      __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
-            const unsigned long long avail = pk_end - pk_next;
-            unsigned long long nlo = 0, nhi = 0;
-            if (cnt > avail && !q_done) {
-                const int leader = __ffsll((long long)need) - 1;
-                unsigned long long base = 0;
-                if (lane == leader)
-                    base = __hip_atomic_fetch_add(P.head, (unsigned long long)kPacket, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT);
-                base = readlane64(base, leader);
-                nlo = base < P.n_photons ? base : P.n_photons;
-                nhi = base + kPacket < P.n_photons ? base + kPacket : P.n_photons;
-                if (nhi >= P.n_photons) q_done = true;
-            }
-            bool got = false;
-            unsigned long long id = 0;
-            if (!alive) {
-                if (rank < avail) { id = pk_next + rank; got = true; }
-                else if (rank - avail < nhi - nlo) { id = nlo + (rank - avail); got = true; }
-            }
-            if (cnt <= avail) pk_next += cnt;
-            else {
-                unsigned long long used = cnt - avail;
-                if (used > nhi - nlo) used = nhi - nlo;
-                pk_next = nlo + used; pk_end = nhi;
-            }
-
-            if (got) {
-                // ------------- emission: role of sample_light, S/light_samples.py:90-116
-                pid = P.photon_offset + id;
-                alive = true; w = 1; sleft = 0; step = 0; grp = 0;
-                max_steps = P.max_steps;
-                if constexpr (!TABLE) photon_stream(P.seed, pid, &rng);
-                if (P.src_type == LT_SRC_COSINE_QUAD) {
-                    R u4[4];
-                    if constexpr (TABLE) {
-                        const double* t = P.table + (id * P.table_steps + grp) * 4;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) u4[k] = (R)(1.0 - t[k]);
-                    } else {
-                        u4[0] = Mx<R>::uniform(&rng);
-#pragma unroll
-                        for (int k = 1; k < 4; k++) u4[k] = Mx<R>::uniform32(&rng);
-                    }
-                    grp++;
-                    R nrm[3] = {(R)P.src_dir[0], (R)P.src_dir[1], (R)P.src_dir[2]};
-                    R wi[3] = {-nrm[0], -nrm[1], -nrm[2]};
-                    R o4[4];
-                    cosine_hemi(nrm, wi, u4[2], u4[3], o4);
-                    ux = o4[0]; uy = o4[1]; uz = o4[2];
-                    px = (R)P.src_pos[0] + u4[0] * (R)P.src_e1[0] + u4[1] * (R)P.src_e2[0] + eps * o4[0];  // :96
-                    py = (R)P.src_pos[1] + u4[0] * (R)P.src_e1[1] + u4[1] * (R)P.src_e2[1] + eps * o4[1];
-                    pz = (R)P.src_pos[2] + u4[0] * (R)P.src_e1[2] + u4[1] * (R)P.src_e2[2] + eps * o4[2];
-                } else {
-                    px = (R)P.src_pos[0]; py = (R)P.src_pos[1]; pz = (R)P.src_pos[2];
-                    ux = (R)P.src_dir[0]; uy = (R)P.src_dir[1]; uz = (R)P.src_dir[2];
-                }
-                if constexpr (!MESH) {
-                    cur = -1;
-                    for (int l = 0; l < P.n_layers; l++)
-                        if (pz >= s_zb[l] && pz < s_zb[l + 1]) { cur = l; break; }
-                    if (cur < 0) {
-                        atomicAdd(&s_cnt[CW_ESC_TOP], (double)w); alive = false;
-                    } else if (P.src_type == LT_SRC_PENCIL && pz == s_zb[0] && uz > 0) {
-                        R n2 = s_med[s_lm[0]].n, n1 = (R)P.n_above;
-                        if (n1 != n2) {  // specular reflection on entering the first layer
-                            R d[3] = {ux, uy, uz}, nf[3] = {0, 0, -1}, ct, refr[3];
-                            R Rs = boundary(d, nf, n1, n2, &ct, refr);
-                            atomicAdd(&s_cnt[CW_SPECULAR], (double)(w * Rs));
-                            w -= w * Rs;
-                            if (!(w > 0)) alive = false;
-                            ux = refr[0]; uy = refr[1]; uz = refr[2];
-                        }
-                    }
-                } else {
-                    cur = P.start_medium;
-                }
-                nv = 0;
-                if (P.vertices) {
-                    P.vertex_counts[id] = 0;
-                    if (alive) record_vertex<R>(P, id, nv, px, py, pz, ux, uy, uz, w, LT_VERTEX_LIGHT, cur, 0u);
-                }
-                if constexpr (TABLE) {
-                    unsigned long long cap = P.table_steps > grp ? P.table_steps - grp : 0ull;
-                    if (cap < (unsigned long long)max_steps) max_steps = (unsigned)cap;
-                }
-            }
-        }
-        if (!__any(alive)) break;  // wave-uniform: queue drained and every lane done
-
-        // ---------------- one photon-step ----------------
-        unsigned f_idx = kNoVoxel;  // deposit record leaving the run-length accumulator this step
-        TV f_val = 0;
-        if (alive) {
-            if (step >= max_steps) {
-                atomicAdd(&s_cnt[CW_CAPPED], (double)w); alive = false;
-            } else {
-                step++;
-                acc_steps++;
-                // mesh walks: the clearance of the current cell is a dependent global load; requested here, before the
-                // ~150 instructions of RNG and logarithm, its latency is hidden by the time the hop length is known
-                float clr = -1.0f;   // no grid / outside it: always query
-                if constexpr (MESH) {
-                    if (P.clear) {
-                        const R cx = (px - (R)P.corg[0]) * (R)P.cinv[0], cy = (py - (R)P.corg[1]) * (R)P.cinv[1],
-                                cz = (pz - (R)P.corg[2]) * (R)P.cinv[2];
-                        if (cx >= 0 && cx < (R)P.cnx && cy >= 0 && cy < (R)P.cny && cz >= 0 && cz < (R)P.cnz)
-                            clr = P.clear[((size_t)(int)cz * P.cny + (int)cy) * P.cnx + (int)cx];
-                    }
-                }
-                R u4[4];
-                if constexpr (TABLE) {  // table RNG: S/scene.py:68-69, S/path_tracing_fix1.py:28-29
-                    const double* t = P.table + ((pid - P.photon_offset) * P.table_steps + grp) * 4;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) u4[k] = (R)(1.0 - t[k]);
-                } else {   // xi0 (step length) with 53 bits, xi1..xi3 with 32 bits: 5 XORWOW draws per step
-                    u4[0] = Mx<R>::uniform(&rng);
-#pragma unroll
-                    for (int k = 1; k < 4; k++) u4[k] = Mx<R>::uniform32(&rng);
-                }
-                grp++;
-                const MedD<R>* Mp = &s_med[MESH ? cur : s_lm[cur]];
-                const R mu_t = Mp->mu_t;
-                if (sleft == 0) sleft = Mx<R>::neg_log(u4[0]);
-                const R s = (mu_t > 0) ? sleft * Mp->inv_mu_t : inf;
-
-                // ---- hop: distance to the next boundary ----
-                R tb = inf; int hit_tri = -1;
-                if constexpr (!MESH) {
-                    if (uz != 0) {
-                        const R dz = (uz > 0 ? s_zb[cur + 1] : s_zb[cur]) - pz;   // sign of uz, or 0
-                        // A hop that ends well inside the layer needs no quotient: |dz| > s |uz| (1 + d) with
-                        // d >= 8 ulp implies fl(dz / uz) > s, so `tb <= s` below is false either way and tb is
-                        // not read.  Only lanes within a step of an interface pay for the IEEE division.
-                        const R guard = sizeof(R) == 8 ? (R)(1.0 + 1e-12) : (R)(1.0 + 1e-5);
-                        const bool near = !(Mx<R>::abs(dz) > s * Mx<R>::abs(uz) * guard);
-                        if (__any(near)) {   // wave-uniform skip; the empty asm keeps the quotient from being hoisted
-                            R den = uz;      // back out and turned into a select
-                            asm volatile("" : "+v"(den));
-                            if (near) tb = dz / den;
-                        }
-                    }
-                } else {
-                    // clearance grid: every triangle is farther than `c` from every point of this cell, so a hop of
-                    // length s < c ends before any surface and the traversal is skipped (same result, no query)
-                    const bool query = !(s < (R)clr);
-                    if (query) {
-                        R o[3] = {px, py, pz}, d[3] = {ux, uy, uz}, th;
-                        nearest_bvh(s_tris, s_nodes, P.n_nodes, o, d, s, hit_tri, th);
-                        if (hit_tri >= 0) tb = th;
-                    }
-                }
-                const bool at_boundary = MESH ? (hit_tri >= 0) : (tb <= s);
-                if (!at_boundary && !(s < inf)) {
-                    atomicAdd(&s_cnt[MESH ? CW_ESC_MESH : CW_CAPPED], (double)w); alive = false;
-                } else if (at_boundary) {
-                    px += ux * tb; py += uy * tb; pz += uz * tb;
-                    sleft -= tb * mu_t;
-                    if (!(sleft > 0)) sleft = 0;
-                    R nf[3], n1 = Mp->n, n2; int next;
-                    if constexpr (!MESH) {
-                        const bool down = uz > 0;
-                        pz = down ? s_zb[cur + 1] : s_zb[cur];
-                        nf[0] = 0; nf[1] = 0; nf[2] = down ? (R)-1 : (R)1;
-                        next = down ? cur + 1 : cur - 1;
-                        if (next < 0) n2 = (R)P.n_above;
-                        else if (next >= P.n_layers) n2 = (R)P.n_below;
-                        else n2 = s_med[s_lm[next]].n;
-                    } else {
-                        const TriD<R>* T = &s_tris[hit_tri];
-                        R tn[3] = {T->n[0], T->n[1], T->n[2]};
-                        R d[3] = {ux, uy, uz};
-                        R dn = dot3(d, tn);
-                        R sg = dn > 0 ? (R)-1 : (R)1;  // S/path_tracing_fix1.py:48-51
-                        nf[0] = sg * tn[0]; nf[1] = sg * tn[1]; nf[2] = sg * tn[2];
-                        next = dn > 0 ? T->med_front : T->med_back;
-                        n2 = next >= 0 ? s_med[next].n : n1;  // exterior: index matched
-                    }
-                    R d[3] = {ux, uy, uz}, ct, refr[3];
-                    R Rf = boundary(d, nf, n1, n2, &ct, refr);
-                    if (P.vertices)
-                        record_vertex<R>(P, pid - P.photon_offset, nv, px, py, pz, ux, uy, uz, w,
-                                         (u4[3] <= Rf) ? LT_VERTEX_REFLECTIVE : LT_VERTEX_TRANSMISSIVE, cur, step);
-                    if (u4[3] <= Rf) {  // reflect: S/brdf.py:8-9
-                        R ro[3]; reflect_walk(d, nf, ro);
-                        ux = ro[0]; uy = ro[1]; uz = ro[2];
-                        if constexpr (MESH) { px += eps * nf[0]; py += eps * nf[1]; pz += eps * nf[2]; }  // :118
-                    } else {
-                        const bool gone = MESH ? (next < 0) : (next < 0 || next >= P.n_layers);
-                        if (gone) {
-                            const int slot = MESH ? CW_ESC_MESH : (next < 0 ? CW_ESC_TOP : CW_ESC_BOT);
-                            atomicAdd(&s_cnt[slot], (double)w); alive = false;
-                        } else {
-                            ux = refr[0]; uy = refr[1]; uz = refr[2];
-                            if constexpr (MESH) { px -= eps * nf[0]; py -= eps * nf[1]; pz -= eps * nf[2]; }  // :112
-                            cur = next;
-                        }
-                    }
-                } else {
-                    // ---- interaction site: move, drop, spin, roulette ----
-                    px += ux * s; py += uy * s; pz += uz * s;
-                    sleft = 0;
-                    if (P.vertices)
-                        record_vertex<R>(P, pid - P.photon_offset, nv, px, py, pz, ux, uy, uz, w, LT_VERTEX_VOLUME, cur, step);
-                    const R dw = w * Mp->absorb;
-                    const R fx = (px - gx0) * ivx, fy = (py - gy0) * ivy, fz = (pz - gz0) * ivz;
-                    // branch-free: nearly every deposit is inside the grid, so the index is computed for all lanes
-                    // and the run-length accumulator is updated with selects
-                    const bool inside = fx >= 0 && fx < fnx && fy >= 0 && fy < fny && fz >= 0 && fz < fnz;
-                    const unsigned vx = (unsigned)(int)fx, vy = (unsigned)(int)fy, vz = (unsigned)(int)fz;
-                    const unsigned idx = P.log_idx   // log mode: tiled index (see kTileBX); atomic mode: linear index
-                        ? (((((vz >> kTileBZ) * P.log_nty + (vy >> kTileBY)) * P.log_ntx + (vx >> kTileBX)) << kTileShift)
-                           | ((vz & 15u) << 10) | ((vy & 31u) << 5) | (vx & 31u))
-                        : (vz * (unsigned)P.ny + vy) * (unsigned)P.nx + vx;
-                    const TV q = tally_quantum<TALLY, R>(dw);
-                    const bool same = inside && idx == pend_idx;
-                    const bool flush = inside && !same;
-                    f_idx = flush ? pend_idx : kNoVoxel; f_val = pend_val;
-                    pend_val = same ? pend_val + q : (flush ? q : pend_val);
-                    pend_idx = flush ? idx : pend_idx;
-                    acc_abs += inside ? (double)dw : 0.0;
-                    acc_lost += inside ? 0.0 : (double)dw;
-                    w -= dw;
-                    if (!(w > 0)) alive = false;
-                    else {
-                        R u[3] = {ux, uy, uz};
-                        spin(u, hg_sample(u4[1], Mp->g, Mp->one_m_g2, Mp->one_p_g2, Mp->inv_2g), u4[2]);
-                        ux = u[0]; uy = u[1]; uz = u[2];
-                        if (w < (R)1e-4) {  // weight roulette; shape of S/path_tracing_fix1.py:126-132
-                            if (u4[3] <= (R)0.1) { atomicAdd(&s_cnt[CW_ROULETTE], -9.0 * (double)w); w *= (R)10; }
-                            else { atomicAdd(&s_cnt[CW_ROULETTE], (double)w); alive = false; }
-                        }
-                    }
-                }
-            }
-        }
-        // wave-uniform point: send this step's records to the grid (atomics) or to the deposit log
-        emit_deposit<TALLY>(P, f_idx != kNoVoxel, f_idx, f_val, lg_cur, lg_end, lg_chunk, s_hist);
-    }
-    emit_deposit<TALLY>(P, pend_idx != kNoVoxel, pend_idx, pend_val, lg_cur, lg_end, lg_chunk, s_hist);
-    if (P.log_idx && lg_chunk != kNoVoxel && (threadIdx.x & 63) == 0) P.log_fill[lg_chunk] = lg_cur - lg_chunk * kLogChunk;
-
-    // ---------------- flush counters ----------------
-    const double wa = wave_sum(acc_abs), wl = wave_sum(acc_lost);
-    const unsigned long long ws = wave_sum(acc_steps);
-    if (lane == 0) {
-        atomicAdd(&s_cnt[CW_ABSORBED], wa);
-        atomicAdd(&s_cnt[CW_LOST], wl);
-        __hip_atomic_fetch_add(&P.counters->steps, ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (P.log_idx)
-        for (unsigned t = threadIdx.x; t < P.log_n_tiles; t += blockDim.x)
-            if (s_hist[t]) __hip_atomic_fetch_add(&P.log_hist[t], s_hist[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x == 0 && threadIdx.x == 8)
-        __hip_atomic_fetch_add(&P.counters->photons, P.n_photons, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x < 8)
-        __hip_atomic_fetch_add(&P.counters->w[threadIdx.x], s_cnt[threadIdx.x], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-}
+#define LT_WALK_NAME walk_kernel
+#define LT_WALK_BATCH 0
+#include "lt_walk_kernel.inc"
+#undef LT_WALK_NAME
+#undef LT_WALK_BATCH
+#define LT_WALK_NAME walk_kernel_q
+#define LT_WALK_BATCH 1
+#include "lt_walk_kernel.inc"
+#undef LT_WALK_NAME
+#undef LT_WALK_BATCH
 
 // ---------------------------------------------------------------------------
 // variant dispatch
@@ -947,9 +629,17 @@ template <typename R, int GEOM, bool TABLE>
 static WalkFn pick_tally(int tally)
 {
     switch (tally) {
-    case LT_TALLY_F32: if constexpr (!TABLE) return walk_kernel<R, GEOM, TABLE, LT_TALLY_F32>; else return nullptr;
-    case LT_TALLY_F64: return walk_kernel<R, GEOM, TABLE, LT_TALLY_F64>;
-    case LT_TALLY_U64FX: return walk_kernel<R, GEOM, TABLE, LT_TALLY_U64FX>;
+    // slabs: walk_kernel; meshes: walk_kernel_q (the same body with batched BVH queries, lt_walk_kernel.inc)
+    case LT_TALLY_F32:
+        if constexpr (TABLE) return nullptr;
+        else if constexpr (GEOM == 0) return walk_kernel<R, GEOM, TABLE, LT_TALLY_F32>;
+        else return walk_kernel_q<R, GEOM, TABLE, LT_TALLY_F32>;
+    case LT_TALLY_F64:
+        if constexpr (GEOM == 0) return walk_kernel<R, GEOM, TABLE, LT_TALLY_F64>;
+        else return walk_kernel_q<R, GEOM, TABLE, LT_TALLY_F64>;
+    case LT_TALLY_U64FX:
+        if constexpr (GEOM == 0) return walk_kernel<R, GEOM, TABLE, LT_TALLY_U64FX>;
+        else return walk_kernel_q<R, GEOM, TABLE, LT_TALLY_U64FX>;
     case LT_TALLY_NONE: if constexpr (!TABLE && GEOM == 0) return walk_kernel<R, GEOM, TABLE, LT_TALLY_NONE>; else return nullptr;
     }
     return nullptr;
