@@ -7,9 +7,13 @@
 //     counter (1 returning atomic per 64 photons) -- divergent path lengths are
 //     absorbed by refilling dead lanes, not by launching more threads;
 //   * dead lanes are found with a wave ballot and refilled by ballot rank
-//     (v_mbcnt), so a wave only idles lanes in the final drain;
-//   * rocRAND XORWOW state per lane, re-seeded per photon from (seed, id) so a
-//     photon's uniforms do not depend on which lane / wave / GPU traces it;
+//     (v_mbcnt), four at a time (a refill costs the whole wave ~140 instructions);
+//   * rocRAND XORWOW state per lane, re-seeded per photon from (seed, id) and
+//     warmed up by 8 discarded outputs, so a photon's uniforms do not depend
+//     on which lane / wave / GPU traces it;
+//   * the kernel body lives in lt_walk_kernel.inc and is instantiated twice:
+//     walk_kernel (slabs) and walk_kernel_q (meshes: BVH queries batched per
+//     wave, the one divergent block expensive enough to be worth waiting for);
 //   * media, layer and BVH/triangle tables are staged once per workgroup into
 //     LDS (all lanes read the same few entries: LDS broadcast);
 //   * deposits: consecutive same-voxel deposits of a lane are merged in
