@@ -160,6 +160,10 @@ def test_xorwow_known_answer():
     initial state scrambled by the two prime multiples; stream is deterministic."""
     a, b = O.rng_raw(0, 0, 8), O.rng_raw(0, 0, 8)
     assert np.array_equal(a, b)
+    # the per-photon stream is DEFINED as: xorwow seeded with splitmix64(seed, id), first 8 outputs discarded
+    # (DESIGN.md section 2: why); pinned so that a change of that definition cannot slip in unnoticed
+    assert list(O.rng_raw(0, 0, 4)) == [1103228482, 1806729144, 594538611, 1790927445]
+    assert list(O.rng_raw(12345, 678, 4)) == [1926655411, 2439364131, 499062357, 4025134735]
     assert len(set(O.rng_raw(0, i, 1)[0] for i in range(1000))) == 1000  # distinct streams per photon
     # statistical sanity of the uniforms
     v = np.concatenate([O.rng_raw(5, i, 256) for i in range(400)]).astype(np.float64) / 2 ** 32
