@@ -651,3 +651,85 @@ def test_published_values_at_gpu_scale(ctx):
     c = ctx.read_counters()
     assert abs(c["w_specular"] / n3 - (0.37 / 2.37) ** 2) < 1e-12
     assert abs(c["w_escaped_top"] / n3 - 0.2378) < 1.0e-3 and abs(c["w_escaped_bottom"] / n3 - 0.0965) < 1.2e-3
+
+
+# ---------------------------------------------------------------- randomised scenes
+def test_random_layered_scenes_match_oracle(ctx):
+    """Thirty random layered problems (1-4 layers, matched and mismatched indices, thin and thick, odd grids, beams
+    that start inside the stack or tilted), both tally paths: fixed-point tallies and step counts equal the oracle's."""
+    rs = np.random.RandomState(2025)
+    for case in range(30):
+        nl = int(rs.randint(1, 5))
+        media = [(float(rs.uniform(0.01, 2.0)), float(rs.uniform(0.5, 60.0)), float(rs.choice([0.0, 0.3, 0.8, 0.95, -0.4])),
+                  float(rs.choice([1.0, 1.33, 1.4, 1.5]))) for _ in range(nl)]
+        thick = rs.uniform(0.02, 0.6, size=nl)
+        zb = np.concatenate([[0.0], np.cumsum(thick)])
+        if rs.rand() < 0.4:
+            zb[-1] = np.inf
+        shape = tuple(int(x) for x in rs.randint(1, 41, size=3))
+        voxel = tuple(float(x) for x in rs.uniform(0.01, 0.2, size=3))
+        origin = (-shape[0] * voxel[0] / 2 + float(rs.uniform(-0.05, 0.05)), -shape[1] * voxel[1] / 2, float(rs.uniform(-0.05, 0.05)))
+        d = np.array([rs.uniform(-0.4, 0.4), rs.uniform(-0.4, 0.4), 1.0]); d /= np.linalg.norm(d)
+        z0 = 0.0 if rs.rand() < 0.5 else float(rs.uniform(0.0, float(np.sum(thick))) * 0.9)
+        src = dict(type=0, pos=(float(rs.uniform(-0.1, 0.1)), 0.0, z0), dir=tuple(float(x) for x in d), extra=(0.0,) * 6,
+                   start_medium=0)
+        prob = S.Problem(media, shape, origin, voxel, source=src, max_steps=int(rs.choice([1000000, 300])),
+                         layers=dict(z_bounds=zb, medium_idx=list(rs.permutation(nl)), n_above=float(rs.choice([1.0, 1.33])),
+                                     n_below=float(rs.choice([1.0, 1.5]))))
+        n = int(rs.randint(1, 1500))
+        _, fxo, co = prob.oracle().run(n, seed=case, threads=4, want_fx=True, want_f64=False)
+        for mode in ("atomic", "log"):
+            prob.apply(ctx, "u64fx"); ctx.set_tally_mode(mode)
+            ctx.zero_tally(); ctx.launch(n, seed=case); ctx.sync()
+            c = ctx.read_counters()
+            assert c["steps"] == co["steps"], (case, mode, c["steps"], co["steps"])
+            assert np.array_equal(ctx.read_grid_raw().reshape(-1), fxo.reshape(-1)), (case, mode)
+            for k in ("w_absorbed", "w_escaped_top", "w_escaped_bottom", "w_specular", "w_capped", "w_lost_outside_grid"):
+                assert abs(c[k] - co[k]) < 1e-9 * max(1, n), (case, mode, k, c[k], co[k])
+    ctx.set_tally_mode(2)
+
+
+def test_random_mesh_scenes_match_oracle(ctx):
+    """Randomised closed-box + sphere scenes (sphere size, position, tessellation, media, indices, source, BVH split
+    method drawn at random), both tally paths, f64 walk: fixed-point tallies and step counts equal the oracle's.  These
+    run through walk_kernel_q, whose lanes wait for one another before a BVH query."""
+    from light_transport_amd.src.io import triangles_from_mesh
+    from light_transport_amd.src import cornell_box as cb, constants as K, bvh_new as B
+    rs = np.random.RandomState(77)
+    for case in range(10):
+        dim = float(rs.uniform(1.0, 5.0))
+        walls = cb.get_cornell_box(dim, K.GLASS_MAT, K.GLASS_MAT, K.GLASS_MAT) + cb.get_front_wall(dim, K.GLASS_MAT) \
+            + cb.get_light_quad(dim, K.GLASS_MAT)
+        for t in walls:
+            t.med_front, t.med_back = 0, -1
+        radius = float(rs.uniform(0.2, 0.45)) * dim
+        centre = tuple(float(x) for x in rs.uniform(-0.4, 0.4, size=3) * dim)
+        vs, fs = S.icosphere(int(rs.randint(0, 3)), radius, centre)
+        ball = triangles_from_mesh(vs, fs, K.GLASS_MAT)
+        for t in ball:
+            t.med_front, t.med_back = 0, 1
+        ordered, linear = B.build_linear_bvh(walls + ball, int(rs.randint(0, 2)))
+        mesh = dict(verts=B.triangles_array(ordered), med_front=np.array([t.med_front for t in ordered], np.int32),
+                    med_back=np.array([t.med_back for t in ordered], np.int32), nodes=B.linear_bvh_arrays(linear))
+        media = [(float(rs.uniform(0.02, 0.5)), float(rs.uniform(1.0, 20.0)), float(rs.choice([0.0, 0.8, 0.9])), 1.0),
+                 (float(rs.uniform(0.1, 2.0)), float(rs.uniform(1.0, 30.0)), float(rs.choice([0.0, 0.7, 0.95])),
+                  float(rs.choice([1.0, 1.37, 1.5])))]
+        if rs.rand() < 0.5:
+            src = dict(type=1, pos=(-0.25 * dim, dim, -0.25 * dim), dir=(0.0, -1.0, 0.0),
+                       extra=(0.5 * dim, 0.0, 0.0, 0.0, 0.0, 0.5 * dim), start_medium=0)
+        else:
+            d = rs.normal(size=3); d /= np.linalg.norm(d)
+            src = dict(type=0, pos=(0.9 * dim * float(rs.uniform(-1, 1)), -0.95 * dim, 0.0), dir=tuple(float(x) for x in d),
+                       extra=(0.0,) * 6, start_medium=0)
+        ng = int(rs.randint(8, 40))
+        prob = S.Problem(media, (ng, ng, ng), (-dim,) * 3, (2 * dim / ng,) * 3, mesh=mesh, source=src)
+        n = int(rs.randint(200, 2500))
+        _, fxo, co = prob.oracle().run(n, seed=100 + case, threads=4, want_fx=True, want_f64=False)
+        for mode in ("atomic", "log"):
+            prob.apply(ctx, "u64fx"); ctx.set_tally_mode(mode)
+            ctx.zero_tally(); ctx.launch(n, seed=100 + case); ctx.sync()
+            c = ctx.read_counters()
+            assert c["steps"] == co["steps"], (case, mode, c["steps"], co["steps"])
+            assert np.array_equal(ctx.read_grid_raw().reshape(-1), fxo.reshape(-1)), (case, mode)
+            assert abs(c["w_escaped_mesh"] - co["w_escaped_mesh"]) < 1e-9 * n and abs(c["w_absorbed"] - co["w_absorbed"]) < 1e-9 * n
+    ctx.set_tally_mode(2)
