@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(kPartThreads) k_log_part(LogReduceParams L)
     if (item >= n_items) break;
     const uint32_t nb1 = (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2;
     const uint32_t mask2 = (1u << L.bits2) - 1;
+    const bool final_pass = PASS == 2 || L.bits2 == 0;
     const uint32_t* in_idx; const TV* in_val; uint32_t* out_idx; TV* out_val; uint32_t* cursor; uint32_t nb;
     uint32_t lo, n;
     if (PASS == 1) {
@@ -223,7 +224,11 @@ __global__ void __launch_bounds__(kPartThreads) k_log_part(LogReduceParams L)
         const uint32_t t = tile_of(kk);
         const uint32_t d = PASS == 1 ? (t >> L.bits2) : (t & mask2);
         const uint32_t dst = s_gbase[d] + (p - s_off[d]);
-        out_idx[dst] = kk; out_val[dst] = s_val[p];
+        // the last pass leaves a tile's records together, so only the 14-bit position inside the tile is kept: 2 bytes
+        // instead of 4 written here and read by the reduce
+        if (final_pass) reinterpret_cast<uint16_t*>(out_idx)[dst] = (uint16_t)(kk & (kTileSize - 1));
+        else out_idx[dst] = kk;
+        out_val[dst] = s_val[p];
     }
     __syncthreads();   // LDS is reused by the next item
   }
@@ -255,7 +260,7 @@ __global__ void __launch_bounds__(kReduceThreads) k_log_reduce(LogReduceParams L
     __syncthreads();
     const uint32_t t = s_item[0], lo = s_item[1], hi = s_item[2];
     const bool shared_tile = L.items_r[t + 1] - L.items_r[t] > 1;
-    const uint32_t* idx = L.log_idx;
+    const uint16_t* idx = reinterpret_cast<const uint16_t*>(L.log_idx);   // in-tile positions, see k_log_part's last pass
     const TV* val = reinterpret_cast<const TV*>(L.log_val);
     // four independent records in flight per lane (the tile pins the workgroup at 8 waves per CU, so memory-level
     // parallelism has to come from the instruction stream)
