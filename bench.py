@@ -261,7 +261,8 @@ def main():
         if stages:
             # per-kernel figures of the job, live from HIP events on each ctx's stream over the timed region
             rec = float(np.mean([x["records"] for x in stages]))
-            rb = 4 + {"f32": 4, "f64": 8, "u64fx": 8}[args.tally]          # bytes per deposit record
+            rb = 4 + {"f32": 4, "f64": 8, "u64fx": 8}[args.tally]          # bytes per deposit record in the log
+            pb = 2 * rb - 2                                                    # partition: read rb, write rb - 2
             w, p_, r_ = (float(np.mean([x[k] for x in stages])) for k in ("walk_ms", "partition_ms", "reduce_ms"))
             shared = " (shares the device with the other job in flight: durations overlap)" if depth > 1 else ""
             out["roofline"]["kernels"] = [
@@ -269,19 +270,19 @@ def main():
                  "note": "349 VALU instr per photon-step (PMC SQ_INSTS_VALU, profiles/r01e_pmc_sq.csv); writes the %.1f GB deposit log%s"
                          % (rec * rb / 1e9, shared),
                  "photon_steps_per_sec": steps_one_launch / (w * 1e-3)},
-                {"kernel": "k_log_part", "ms": p_, "bound": "hbm", "achieved": 2 * rb * rec / (p_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "frac": 2 * rb * rec / (p_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "note": "algorithmic: every record read once and written once" + shared},
-                {"kernel": "k_log_reduce", "ms": r_, "bound": "hbm", "achieved": rb * rec / (r_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "frac": rb * rec / (r_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "note": "algorithmic: every record read once" + shared}]
+                {"kernel": "k_log_part", "ms": p_, "bound": "hbm", "achieved": pb * rec / (p_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": pb * rec / (p_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "note": "algorithmic: every record read once (%d B) and written once (%d B: 2-byte in-tile position)" % (rb, rb - 2) + shared},
+                {"kernel": "k_log_reduce", "ms": r_, "bound": "hbm", "achieved": (rb - 2) * rec / (r_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": (rb - 2) * rec / (r_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "note": "algorithmic: every record read once (%d B)" % (rb - 2) + shared}]
             out["roofline"]["deposit_records_per_launch"] = rec
         if alone:
             alone["note"] = ("one job alone on the device (default launch geometry, 4 waves/SIMD), 2 launches after the timed "
                              "region: single-job latency and kernel durations nothing overlaps")
             if "partition_ms" in alone and stages:
-                alone["k_log_part_frac"] = 2 * rb * rec / (alone["partition_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-                alone["k_log_reduce_frac"] = rb * rec / (alone["reduce_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                alone["k_log_part_frac"] = pb * rec / (alone["partition_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                alone["k_log_reduce_frac"] = (rb - 2) * rec / (alone["reduce_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["roofline"]["one_job_alone"] = alone
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
