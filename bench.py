@@ -13,7 +13,8 @@ the log-structured tally: walk -> deposit log -> tile partition -> LDS reduce) a
 photon-id ranges (weak scaling: 1e7 photons per GPU); there is no other
 collective.  Inputs are synthetic by nature (the scene is ~100 bytes of constants,
 resident in HBM before the timed region).  By default two jobs are in flight per
-GPU (--inflight 2: two contexts, i.e. two HIP streams with their own grid and
+GPU (after a short untimed probe has confirmed that they overlap; --inflight 2
+forces it, --inflight 1 forbids it: two contexts, i.e. two HIP streams with their own grid and
 deposit log, take the steps in turn), so that the bandwidth-bound log reduction of
 one job runs beside the VALU-bound walk of the next; every step is still a
 complete job and all K of them finish inside the timed region.
@@ -109,8 +110,9 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--tally-mode", default="log", choices=["log", "atomic", "auto"],
                     help="log: deposit log + tile partition + LDS reduce (default); atomic: one global atomic per deposit")
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="jobs in flight per GPU (contexts taking the steps in turn); 1 = strictly one job at a time")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="jobs in flight per GPU (contexts taking the steps in turn); 1 = strictly one job at a time; "
+                         "0 (default) = 2 if a short untimed probe confirms that two jobs overlap on this device, else 1")
     ap.add_argument("--no-alone", action="store_true",
                     help="skip the single-job reference launches after the timed region (keeps a rocprofv3 kernel "
                          "trace of this command to launches of the timed regime only)")
@@ -137,18 +139,58 @@ def main():
     # reduction of one job runs beside the VALU-bound walk of the next.  The walk is then launched at 2 workgroups per
     # CU per job: two walks together fill the 4 waves/SIMD the register file holds, one walk leaves room for the
     # other job's partition / reduce workgroups.
-    depth = max(1, args.inflight)
-    bpc = args.blocks_per_cu or ((3 if args.f32_walk else 2) if depth > 1 else 0)   # f32 walk: 96 VGPRs, 5 waves/SIMD fit
+    auto_depth = args.inflight <= 0
+    depth = 2 if auto_depth else args.inflight
+
+    def walk_bpc(d):
+        return args.blocks_per_cu or ((3 if args.f32_walk else 2) if d > 1 else 0)   # f32 walk: 96 VGPRs, 5 waves/SIMD fit
+
+    def set_geometry(c, d):
+        b = walk_bpc(d)
+        c.set_launch_config(b, args.threads or (256 if b else 0))
+
     ctxs = []
     for _ in range(depth):
         c = lt.Context(local_rank)
         configure(c, args.tally)
         c.set_tally_mode(args.tally_mode)
-        if bpc or args.threads:
-            c.set_launch_config(bpc, args.threads or 256)
+        set_geometry(c, depth)
         if args.tally_mode != "atomic":
             c.reserve_log(args.photons)   # scratch allocation is set-up, not part of a step (matters when --warmup 0)
         ctxs.append(c)
+    probe = None
+    if auto_depth:
+        # Untimed probe: does the device really run two jobs side by side?  (It does not when the two contexts' streams
+        # share a hardware queue, see GPU_MAX_HW_QUEUES above.)  One job at a time on ctx 0 against four jobs in turn.
+        def run_jobs(cs, n):
+            for c in cs:
+                c.sync()
+            t0 = time.perf_counter()
+            for k in range(n):
+                c = cs[k % len(cs)]
+                if k >= len(cs):
+                    c.sync()
+                c.zero_tally(); c.launch(args.photons, seed=900 + k, photon_offset=rank * args.photons, f32_walk=args.f32_walk)
+            for c in cs:
+                c.sync()
+            return (time.perf_counter() - t0) / n * 1e3
+        set_geometry(ctxs[0], 1)
+        run_jobs(ctxs[:1], 1)
+        t_one = run_jobs(ctxs[:1], 2)
+        set_geometry(ctxs[0], 2)
+        run_jobs(ctxs, 2)
+        t_two = run_jobs(ctxs, 4)
+        use_two = t_two < 0.97 * t_one
+        if distributed:     # every rank must take the same path: the collectives are issued per context in turn
+            flag = torch.tensor([1 if use_two else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            use_two = bool(flag.item())
+        probe = {"one_at_a_time_ms": t_one, "two_in_flight_ms": t_two, "chosen": 2 if use_two else 1}
+        if not use_two:
+            ctxs.pop().close()
+            depth = 1
+            set_geometry(ctxs[0], 1)
+    bpc = walk_bpc(depth)
     info = ctxs[0].device_info()
     per_gpu = args.photons
     offset = rank * per_gpu     # disjoint id ranges; streams depend on (seed, id) only
@@ -211,7 +253,7 @@ def main():
     alone = None
     if rank == 0 and depth > 1 and not args.no_alone:
         c = ctxs[0]
-        c.set_launch_config(args.blocks_per_cu, args.threads or (256 if args.blocks_per_cu else 0))
+        set_geometry(c, 1)
         ms = []
         for k in range(3):
             c.zero_tally(); c.launch(per_gpu, seed=500 + k, photon_offset=offset, f32_walk=args.f32_walk); c.sync()
@@ -248,7 +290,7 @@ def main():
             "config": {"workload": "C2: %.0e photons per GPU, homogeneous semi-infinite slab (mu_a=0.1, mu_s=10, g=0.9, "
                                    "n=1), %d^3 voxel grid (%.1f mm), pencil beam" % (per_gpu, GRID_N, VOXEL),
                        "tally": args.tally, "tally_mode": args.tally_mode, "rng": "rocRAND XORWOW, re-seeded per photon",
-                       "jobs_in_flight": depth, "walk_workgroups_per_cu": bpc or "occupancy",
+                       "jobs_in_flight": depth, "walk_workgroups_per_cu": bpc or "occupancy", "inflight_probe": probe,
                        "parallelism": "photon-id sharding x%d, RCCL reduce of the grid to rank 0 per step" % world
                        if world > 1 else "single GPU", "device": info["name"], "cus": info["cus"],
                        "clock_mhz": info["clock_mhz"], "hbm_gib": round(info["hbm_bytes"] / 2 ** 30, 1)},
