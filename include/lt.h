@@ -140,16 +140,34 @@ int lt_set_launch_config(lt_ctx* ctx, int blocks_per_cu, int threads_per_block);
 /* how deposits reach the grid.  LT_MODE_ATOMIC: one no-return global atomic per
  * deposit record.  LT_MODE_LOG: the walk appends records to a coalesced log in
  * HBM which is radix-partitioned by grid tile and reduced tile by tile in LDS
- * (no global atomics); photons are traced in batches sized to log_bytes
- * (0 keeps the current budget; default: a quarter of the device memory, at most 64 GiB).  Results are identical for the
- * u64 fixed-point tally and equal up to summation order for float tallies.
- * Table RNG, vertex capture and grids beyond 2^28 voxels use the atomic path. */
+ * (no global atomics); photons are traced in batches sized to log_bytes, the
+ * budget for all deposit logs of the ctx and their ping-pong copies (0 restores
+ * the default: a quarter of the device memory, at most 64 GiB).  A log that turns
+ * out too small diverts the excess records to atomics -- speed, never
+ * correctness (lt_last_log_info reports how many).  The first launch of a new
+ * scene traces a 16384-photon pilot batch and reads its record rate back (a few
+ * ms on the host) so that logs and batches are sized from a measurement.
+ * Results are identical for the u64 fixed-point tally and equal up to summation
+ * order for float tallies.  Table RNG, vertex capture and grids beyond 65536
+ * tiles (2^30 voxels) use the atomic path. */
 #define LT_MODE_ATOMIC 0
 #define LT_MODE_LOG 1
 #define LT_MODE_AUTO 2 /* default: LOG where the atomic unit would pace the walk (layered slabs, f32 mesh walks), ATOMIC for f64 mesh walks (BVH arithmetic hides the atomics) */
 int lt_set_tally_mode(lt_ctx* ctx, int mode, uint64_t log_bytes);
-/* optional: allocate the deposit log for launches of up to n_photons now (otherwise the first launch does it) */
+/* optional: allocate the deposit log(s) for launches of up to n_photons now (otherwise the first launch does it) */
 int lt_reserve_log(lt_ctx* ctx, uint64_t n_photons);
+/* Overlap inside ONE lt_launch (log mode).  lanes = 2: the launch is cut into
+ * sub-batches that alternate between two streams of the ctx, each with its own
+ * deposit log, so that the bandwidth-bound reduction of batch k runs beside the
+ * VALU-bound walk of batch k+1 (role of Numba's thread pool working through one
+ * render_scene call, path_tracing_fix1.py:139-148: the caller still makes one
+ * call).  lanes = 1: one stream, batches back to back.  lanes = 0 (default):
+ * launches of >= 2^21 photons whose geometry the caller has not pinned
+ * (lt_set_launch_config) try both once and keep the faster.  The ctx stream
+ * joins both lanes before lt_launch returns, so everything ordered on lt_stream
+ * (readback, lt_reduce_grid, lt_zero_tally) stays ordered.  The u64 fixed-point
+ * grid is bit-identical for every setting. */
+int lt_set_overlap(lt_ctx* ctx, int lanes);
 
 /* ---- run --------------------------------------------------------------- */
 /* role of render_scene (path_tracing_fix1.py:139-169): trace photons
@@ -169,10 +187,14 @@ int lt_sync(lt_ctx* ctx);
  * lt_launch (HIP events on the ctx stream); valid after lt_sync. */
 int lt_last_kernel_ms(lt_ctx* ctx, double* ms);
 int lt_zero_tally(lt_ctx* ctx); /* zero grid + counters (async)           */
-/* device milliseconds of the stages of the LAST batch of the last log-mode
- * lt_launch: [0] walk kernel, [1] counts readback + scan, [2] partition
- * pass(es), [3] tile reduce; deposit records and batches of that launch. */
+/* device milliseconds per stage, summed over the batches (and lanes) of the last
+ * log-mode lt_launch: [0] walk kernel, [1] scan, [2] partition pass(es), [3] tile
+ * reduce (with two lanes the stages of different batches overlap in time);
+ * deposit records and batches of that launch. */
 int lt_last_log_stages(lt_ctx* ctx, double ms_out[4], uint64_t* records, uint64_t* batches);
+/* bookkeeping of the last log-mode lt_launch (blocks until it has finished): records written to the
+ * deposit log, records that found it full and went to the grid as atomics, batches, lanes used */
+int lt_last_log_info(lt_ctx* ctx, uint64_t* records, uint64_t* overflow_records, uint64_t* batches, int* lanes);
 
 /* ---- readback ---------------------------------------------------------- */
 /* blocking D2H of the raw tally ([nz][ny][nx], dtype as set) */

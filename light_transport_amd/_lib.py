@@ -28,7 +28,8 @@ SYMBOLS = [
     "lt_grid_device_ptr", "lt_counters_device_ptr", "lt_stream", "lt_reduce_grid", "lt_intersect_rays",
     "lt_triangle_intersect", "lt_intersect_bounds", "lt_eval", "lt_rng_raw", "lt_device_info",
     "lt_set_surface_materials", "lt_set_lights", "lt_render_surface", "lt_set_vertex_capture", "lt_read_vertices",
-    "lt_set_tally_mode", "lt_last_log_stages", "lt_reserve_log", "lt_render_surface_old",
+    "lt_set_tally_mode", "lt_last_log_stages", "lt_reserve_log", "lt_render_surface_old", "lt_set_overlap",
+    "lt_last_log_info",
 ]
 
 # lt_vertex as a NumPy record (72 bytes, same layout as the C struct)
@@ -227,6 +228,18 @@ class Context:
         m = {"atomic": 0, "log": 1, "auto": 2}[mode] if isinstance(mode, str) else int(mode)
         self._ck(lib().lt_set_tally_mode(self._h, C.c_int(m), C.c_uint64(int(log_bytes))), "lt_set_tally_mode")
 
+    def set_overlap(self, lanes=0):
+        """Overlap inside one launch: 2 = sub-batches alternate between two streams of the ctx (one batch's log
+        reduction runs beside the next batch's walk), 1 = one stream, 0 = auto (try both once, keep the faster)."""
+        self._ck(lib().lt_set_overlap(self._h, C.c_int(int(lanes))), "lt_set_overlap")
+
+    def last_log_info(self):
+        """dict(records, overflow_records, batches, lanes) of the last log-mode launch, or None."""
+        rec, ovf, bat, lanes = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
+        if lib().lt_last_log_info(self._h, C.byref(rec), C.byref(ovf), C.byref(bat), C.byref(lanes)) != 0:
+            return None
+        return dict(records=rec.value, overflow_records=ovf.value, batches=bat.value, lanes=lanes.value)
+
     def reserve_log(self, n_photons):
         self._ck(lib().lt_reserve_log(self._h, C.c_uint64(int(n_photons))), "lt_reserve_log")
 
@@ -239,6 +252,7 @@ class Context:
                 raise LtError("rng_table must have shape [n_photons, steps, 4]")
             steps = tab.shape[1]
         flags = FLAG_F32_WALK if f32_walk else 0
+        self._captured_max_vertices = getattr(self, "_max_vertices", 0)
         self._ck(lib().lt_launch(self._h, C.c_uint64(int(n_photons)), C.c_uint64(int(photon_offset)),
                                  C.c_uint64(int(seed) & (2 ** 64 - 1)), _dp(tab), C.c_uint64(steps),
                                  C.c_uint32(flags)), "lt_launch")
@@ -340,7 +354,7 @@ class Context:
 
     def read_vertices(self, n_photons):
         """-> (vertices [n_photons, K] record array of VERTEX_DTYPE, counts [n_photons] uint32) of the last launch."""
-        k = getattr(self, "_max_vertices", 0)
+        k = getattr(self, "_captured_max_vertices", 0)     # the K in effect at the capturing launch
         v = np.zeros((int(n_photons), k), dtype=VERTEX_DTYPE)
         cnt = np.zeros(int(n_photons), dtype=np.uint32)
         self._ck(lib().lt_read_vertices(self._h, v.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p),

@@ -47,16 +47,36 @@ struct DevBuf {
 
 }  // namespace
 
+// One lane of the log pipeline: a stream with its own deposit log, ping-pong copy and bookkeeping tables.  A launch
+// uses lane 0 (the ctx stream) alone, or alternates its batches between lanes 0 and 1 so that the bandwidth-bound
+// reduction of one batch runs beside the VALU-bound walk of the next (lt_set_overlap).
+struct LogLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_done = nullptr;          // end of the lane's last batch
+    std::vector<hipEvent_t> evs;           // 5 per batch of the last launch: walk start / end, scan end, partition end, reduce end
+    size_t ev_used = 0;
+    DevBuf log_idx, log_val, tmp_idx, tmp_val, log_fill, meta, hist1, hist, bin_base, bin_cnt, tile_base, tile_cnt, cursor1,
+        cursor2, items2, items_c, items_r, itab, head;
+    size_t alloc_records = 0;              // capacity of the log buffers currently allocated (without the slack)
+    int alloc_elem = 0;
+    void release_log() { log_idx.release(); log_val.release(); tmp_idx.release(); tmp_val.release(); log_fill.release(); alloc_records = 0; }
+    void release_all()
+    {
+        release_log(); meta.release(); hist1.release(); hist.release(); bin_base.release(); bin_cnt.release(); tile_base.release();
+        tile_cnt.release(); cursor1.release(); itab.release();
+        cursor2.release(); items2.release(); items_c.release(); items_r.release(); head.release();
+    }
+};
+
 struct lt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t evs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries of the last log-mode batch
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr;
     bool stages_valid = false;
-    uint64_t last_records = 0, last_batches = 0;
-    bool log_stats_pending = false, last_overflow = false;
-    uint64_t pending_batch = 0;
-    uint32_t pending_cap_chunks = 0;
+    uint64_t last_records = 0, last_overflow = 0, last_batches = 0;
+    int last_lanes = 1;
+    bool log_stats_pending = false;
+    uint64_t pending_photons = 0;
     std::string err;
     hipDeviceProp_t prop;
 
@@ -76,24 +96,24 @@ struct lt_ctx {
     int src_type = LT_SRC_PENCIL, start_medium = 0;
     double src_pos[3] = {0, 0, 0}, src_dir[3] = {0, 0, 1}, src_extra[6] = {0, 0, 0, 0, 0, 0};
     uint32_t max_steps = 1000000;
-    uint32_t max_vertices = 0;
+    uint32_t max_vertices = 0, captured_max_vertices = 0;
     int tally_mode = 2;                 // 0: global atomics, 1: deposit log + partition + tile reduce, 2: auto (default)
-    size_t log_budget = (size_t)16 << 30; // bytes for the log and its ping-pong copy
-    double rec_per_photon = 0.0;        // measured deposit records per photon (sizes the batches)
-    size_t log_alloc_records = 0;       // capacity of the log buffers currently allocated
-    int log_alloc_elem = 0;
-    double last_stage_ms[6] = {0, 0, 0, 0, 0, 0};
+    size_t log_budget = (size_t)16 << 30, default_log_budget = (size_t)16 << 30;   // bytes for the logs and their ping-pong copies
+    double rec_per_photon = 0.0;        // measured deposit records per photon (sizes the logs and the batches)
+    int overlap_mode = 0;               // lt_set_overlap: 0 auto, 1 one lane, 2 two lanes
+    double auto_ms_per_photon[2] = {0.0, 0.0};   // overlap auto: device time per photon measured with 1 / 2 lanes
+    int auto_pending = -1;              // which of the two the launch in flight is measuring (-1: none)
     uint64_t captured_photons = 0;
     int blocks_per_cu = 0, threads_per_block = 0;
 
     // device buffers
     DevBuf d_media[2], d_zb[2], d_lm, d_tris[2], d_nodes[2];  // [0]=f64, [1]=f32
     DevBuf d_grid, d_counters, d_head, d_table, d_scratch_in, d_scratch_out, d_scratch_aux;
-    DevBuf d_mats, d_lights, d_r0, d_r1, d_lc, d_img, d_xy, d_vtx, d_vcnt, d_clear;
+    DevBuf d_mats, d_lights, d_r0, d_r1, d_lc, d_img, d_xy, d_vtx, d_vcnt, d_clear, d_job;
     int cn[3] = {0, 0, 0};
     double corg[3] = {0, 0, 0}, ccell[3] = {1, 1, 1};
     bool have_clear = false;
-    DevBuf d_log_idx, d_log_val, d_tmp_idx, d_tmp_val, d_log_fill, d_log_meta, d_hist, d_tile_base, d_cursor1, d_cursor2, d_items2, d_items_r;
+    LogLane lanes[2];
     bool tables_dirty = true;
     bool timed = false;
 
@@ -114,6 +134,7 @@ struct lt_ctx {
     }
     size_t grid_elem() const { return tally == LT_TALLY_F32 ? 4 : 8; }
     size_t n_vox() const { return (size_t)nx * (size_t)ny * (size_t)nz; }
+    void scene_changed() { rec_per_photon = 0.0; auto_ms_per_photon[0] = auto_ms_per_photon[1] = 0.0; auto_pending = -1; }
 };
 
 #define CHECK_CTX(c) do { if (!(c)) return LT_E_INVALID; } while (0)
@@ -257,21 +278,256 @@ int upload_tables(lt_ctx* c)
     return LT_OK;
 }
 
-// Read back the statistics of the last log-mode batch (chunks claimed, records logged) once the stream has
-// drained, and update the deposit-record rate that sizes the next launch's log and batches.
+// Read back the statistics of the last log-mode launch (records logged, records that overflowed to atomics) once its
+// streams have drained, and update the deposit-record rate that sizes the next launch's logs and batches.
 int collect_log_stats(lt_ctx* c)
 {
     if (!c->log_stats_pending) return LT_OK;
-    uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIP_TRY(c, hipMemcpyAsync(h, c->d_log_meta.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_job.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // the ctx stream has joined every lane of the launch
     c->log_stats_pending = false;
-    c->last_overflow = h[0] > c->pending_cap_chunks;
-    c->last_records = h[2];
-    if (c->pending_batch > 0) {
-        double rate = (double)h[2] / (double)c->pending_batch;
-        if (c->last_overflow) rate *= 2.0;   // part of the batch went through atomics: the true rate is higher
-        c->rec_per_photon = rate > c->rec_per_photon ? rate : 0.5 * (rate + c->rec_per_photon);
+    c->last_records = h[0]; c->last_overflow = h[1];
+    if (c->pending_photons > 0) c->rec_per_photon = (double)(h[0] + h[1]) / (double)c->pending_photons;
+    if (c->auto_pending >= 0) {    // overlap auto: remember what this regime cost per photon
+        float f = 0;
+        if (hipEventElapsedTime(&f, c->ev0, c->ev1) == hipSuccess && c->pending_photons > 0)
+            c->auto_ms_per_photon[c->auto_pending] = (double)f / (double)c->pending_photons;
+        c->auto_pending = -1;
+    }
+    return LT_OK;
+}
+
+// ---- log-structured tally: planning and enqueueing -------------------------------------------------------------
+constexpr uint32_t kMaxLogTiles = 65536;              // tiled record index = tile << 14 | position: 30 bits
+constexpr uint64_t kPilotPhotons = 16384;             // pilot batch that measures a new scene's record rate
+constexpr uint64_t kOverlapMinPhotons = 1ull << 21;   // overlap auto: launches below this stay on one lane
+
+struct LogGeom { uint32_t ntx, nty, ntz, n_tiles, bits2, nb1; };
+
+LogGeom log_geom(const lt_ctx* c)
+{
+    LogGeom g;
+    g.ntx = ((uint32_t)c->nx + 31u) >> kTileBX; g.nty = ((uint32_t)c->ny + 31u) >> kTileBY; g.ntz = ((uint32_t)c->nz + 15u) >> kTileBZ;
+    g.n_tiles = g.ntx * g.nty * g.ntz;   // 32 x 32 x 16-voxel blocks
+    // grids of <= 1024 tiles (256^3): ONE partition pass straight to tiles.  Records cluster in the few dozen tiles
+    // around the source, so the per-tile runs of a 4096-record work item stay long enough to coalesce.  Larger grids:
+    // two passes over digits of <= 7 bits each (<= 1024 level-1 bins).
+    uint32_t b = 0;
+    if (g.n_tiles > 1024) { b = 1; while ((1u << (2 * b)) < g.n_tiles && b < 7) b++; }
+    if (const char* e = std::getenv("LT_LOG_BITS2")) { int v = std::atoi(e); b = v < 0 ? 0u : (v > 7 ? 7u : (uint32_t)v); }
+    while ((g.n_tiles >> b) > 1024 && b < 7) b++;
+    g.bits2 = b;
+    g.nb1 = b ? (g.n_tiles + (1u << b) - 1) >> b : g.n_tiles;
+    return g;
+}
+
+// records behind the capacity that padded tile / bin starts and whole-group loads may touch
+size_t log_slack_records() { return (size_t)kTileAlign * kMaxLogTiles + (size_t)kBinAlign * 1024 + 2 * (size_t)log_part_item(); }
+
+struct LogPlan {
+    int lanes = 1;
+    uint32_t cap_chunks[2] = {0, 0};                   // log capacity each lane may use (allocation capped by the budget)
+    std::vector<std::pair<int, uint64_t>> batches;     // (lane, photons), in launch order
+};
+
+// make lane `ln` hold a log of at least `want` records (not more than `limit`) and its tables
+hipError_t ensure_lane(lt_ctx* c, LogLane& ln, size_t want, size_t limit, const LogGeom& G)
+{
+    hipError_t e;
+    const size_t elem = c->grid_elem();
+    if (ln.alloc_elem != (int)elem) { ln.release_log(); ln.alloc_elem = (int)elem; }
+    if (want > ln.alloc_records) {
+        // grow geometrically so that run-to-run jitter of the record rate does not re-allocate tens of GB
+        size_t grown = want + want / 8;
+        if (grown > limit) grown = limit;
+        grown = (grown / kLogChunk) * kLogChunk;
+        ln.release_log();
+        const size_t n = grown + log_slack_records();
+        if ((e = ln.log_idx.ensure(n * 4)) != hipSuccess) return e;
+        if ((e = ln.tmp_idx.ensure(n * 4)) != hipSuccess) return e;
+        if ((e = ln.log_val.ensure(n * elem)) != hipSuccess) return e;
+        if ((e = ln.tmp_val.ensure(n * elem)) != hipSuccess) return e;
+        if ((e = ln.log_fill.ensure((grown / kLogChunk) * 4)) != hipSuccess) return e;
+        if ((e = ln.itab.ensure((grown / log_part_item() + 1024 + 16) * 16)) != hipSuccess) return e;   // pass-2 item descriptors
+        ln.alloc_records = grown;
+    }
+    const size_t nt = G.n_tiles, n_hist = G.bits2 ? G.nb1 : G.n_tiles;     // bins of the first partition pass
+    if ((e = ln.meta.ensure(LM_WORDS * 4)) != hipSuccess) return e;
+    if ((e = ln.head.ensure(sizeof(unsigned long long))) != hipSuccess) return e;
+    if ((e = ln.hist.ensure(nt * (G.bits2 ? 1 : kLogGroups) * 4)) != hipSuccess) return e;
+    if ((e = ln.hist1.ensure((size_t)G.nb1 * kLogGroups * 4)) != hipSuccess) return e;
+    if ((e = ln.bin_base.ensure(((size_t)G.nb1 + 1) * 4)) != hipSuccess) return e;
+    if ((e = ln.bin_cnt.ensure(((size_t)G.nb1 + 1) * 4)) != hipSuccess) return e;
+    if ((e = ln.tile_base.ensure((nt + 1) * 4)) != hipSuccess) return e;
+    if ((e = ln.tile_cnt.ensure((nt + 1) * 4)) != hipSuccess) return e;
+    if ((e = ln.cursor1.ensure(n_hist * kLogGroups * 4)) != hipSuccess) return e;
+    if ((e = ln.cursor2.ensure(nt * 4)) != hipSuccess) return e;
+    if ((e = ln.items2.ensure(((size_t)G.nb1 + 1) * 4)) != hipSuccess) return e;
+    if ((e = ln.items_c.ensure(((size_t)G.nb1 + 1) * 4)) != hipSuccess) return e;
+    return ln.items_r.ensure((nt + 1) * 4);
+}
+
+// Size the logs for a launch of n photons on `lanes` lanes and cut it into batches.  LT_E_NOMEM: the device cannot
+// hold the logs (the caller falls back to fewer lanes or to atomics).
+int plan_log(lt_ctx* c, uint64_t n, int lanes, LogPlan* plan)
+{
+    const LogGeom G = log_geom(c);
+    const size_t rec_bytes = 4 + c->grid_elem();
+    size_t per_lane = c->log_budget / (2 * rec_bytes) / (size_t)lanes;     // the budget covers log + ping-pong copy of every lane
+    if (per_lane > 0xFF000000ull) per_lane = 0xFF000000ull;                // 32-bit record offsets
+    per_lane = (per_lane / kLogChunk) * kLogChunk;
+    if (per_lane < 16 * (size_t)kLogChunk) return c->fail(LT_E_INVALID, "lt_launch: log budget too small (%zu bytes)", c->log_budget);
+    // no measurement yet (pilot or tiny launch): tissue-like media give 100-400 records per photon
+    const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 400.0;
+    int sub = 8;    // overlapped launches: sub-batches per launch (the last one's reduction has nothing to hide under)
+    if (const char* e = std::getenv("LT_OVERLAP_BATCHES")) { int v = std::atoi(e); if (v >= 2 && v <= 256) sub = v; }
+    const uint64_t b_target = lanes == 1 ? n : (n + (uint64_t)sub - 1) / (uint64_t)sub;
+    // every resident walk wave holds one partly filled chunk: that many chunks are claimed on top of the records' own
+    double waves = 20.0 * (double)c->prop.multiProcessorCount / (double)lanes;          // at most 5 waves per SIMD
+    const double launched = 4.0 * (double)((b_target + 255) / 256);                          // 256-thread workgroups
+    if (launched < waves) waves = launched;
+    const double wave_slack = (double)kLogChunk * waves;
+    const double need = 1.25 * rate * (double)b_target + wave_slack + 1048576.0;
+    size_t want = need < (double)per_lane ? (size_t)need : per_lane;
+    want = ((want + kLogChunk - 1) / kLogChunk) * kLogChunk;
+    size_t cap_use = per_lane;
+    for (int l = 0; l < lanes; l++) {
+        if (ensure_lane(c, c->lanes[l], want, per_lane, G) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int k = 0; k < 2; k++) c->lanes[k].release_log();
+            return LT_E_NOMEM;
+        }
+        // honour the budget even when an earlier, larger allocation is still there
+        const size_t use = c->lanes[l].alloc_records < per_lane ? c->lanes[l].alloc_records : per_lane;
+        plan->cap_chunks[l] = (uint32_t)(use / kLogChunk);
+        if (use < cap_use) cap_use = use;
+    }
+    double fit = 0.8 * ((double)cap_use - wave_slack) / rate;
+    if (fit < 4096.0) fit = 4096.0;
+    plan->lanes = lanes;
+    plan->batches.clear();
+    uint64_t left = n;
+    if (lanes == 1) {
+        while (left > 0) { const uint64_t b = (double)left > fit ? (uint64_t)fit : left; plan->batches.emplace_back(0, b); left -= b; }
+    } else {
+        uint64_t b = (double)b_target > fit ? (uint64_t)fit : b_target;
+        if (b < 1) b = 1;
+        // lane 0 starts with half a batch so that the two lanes fall out of step: from then on one lane's reduction
+        // runs beside the other lane's walk
+        int l = 0;
+        uint64_t first = b / 2 > 0 ? b / 2 : 1;
+        while (left > 0) {
+            const uint64_t take = first ? (first < left ? first : left) : (b < left ? b : left);
+            first = 0;
+            plan->batches.emplace_back(l, take);
+            left -= take; l ^= 1;
+        }
+    }
+    return LT_OK;
+}
+
+// how many lanes this launch uses (lt_set_overlap).  auto: launches that are large enough try two lanes once and one
+// lane once (device time per photon, HIP events), then keep the faster regime for this scene -- two streams only
+// overlap when the runtime gives them separate hardware queues, which a library cannot guarantee.
+int choose_lanes(lt_ctx* c, uint64_t n)
+{
+    c->auto_pending = -1;
+    if (c->overlap_mode == 1) return 1;
+    if (c->overlap_mode == 2) return n >= 8192 ? 2 : 1;
+    if (c->blocks_per_cu > 0 || n < kOverlapMinPhotons) return 1;    // the caller pinned the launch geometry / small job
+    if (c->auto_ms_per_photon[1] <= 0.0) { c->auto_pending = 1; return 2; }
+    if (c->auto_ms_per_photon[0] <= 0.0) { c->auto_pending = 0; return 1; }
+    return c->auto_ms_per_photon[1] < c->auto_ms_per_photon[0] ? 2 : 1;
+}
+
+struct LogRun {
+    lt_ctx* c; WalkParams P; Variant v; LaunchCfg cfg; LogGeom G;
+};
+
+hipError_t lane_event(LogLane& ln, hipStream_t s)
+{
+    if (ln.ev_used == ln.evs.size()) {
+        hipEvent_t ev;
+        hipError_t e = hipEventCreate(&ev);
+        if (e != hipSuccess) return e;
+        ln.evs.push_back(ev);
+    }
+    return hipEventRecord(ln.evs[ln.ev_used++], s);
+}
+
+// Enqueue every batch of `plan` without a host read-back: item counts stay in device memory, the partition / reduce
+// kernels are persistent work loops, and the statistics that size the next launch are read lazily at lt_sync.
+int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches)
+{
+    lt_ctx* c = R.c;
+    const LogGeom& G = R.G;
+    const uint32_t n_hist = G.bits2 ? G.nb1 : G.n_tiles;
+    LaunchCfg cfg = R.cfg;
+    cfg.lds_bytes = walk_lds_bytes(R.v, R.P.n_media, R.P.n_layers, R.P.n_tris, R.P.n_nodes, n_hist);
+    const int resident = walk_max_blocks_per_cu(R.v, cfg.threads, cfg.lds_bytes);
+    if (resident <= 0) return c->fail(LT_E_HIP, "lt_launch: log-mode kernel not resident");
+    // two lanes: each walk takes half of the resident workgroups, so that two walks together fill the register file
+    // and one walk leaves room for the other lane's partition / reduce workgroups
+    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (plan.lanes == 2 ? (resident + 1) / 2 : resident);
+    const unsigned long long cap = (unsigned long long)per_cu * (unsigned long long)c->prop.multiProcessorCount;
+    if (plan.lanes == 2) {
+        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->lanes[1].stream, c->ev_fork, 0));
+    }
+    for (const auto& bt : plan.batches) {
+        LogLane& ln = c->lanes[bt.first];
+        hipStream_t s = ln.stream;
+        uint32_t* meta = (uint32_t*)ln.meta.p;
+        WalkParams P = R.P;
+        P.n_photons = bt.second; P.photon_offset = offset;
+        P.head = (unsigned long long*)ln.head.p;
+        P.log_idx = (uint32_t*)ln.log_idx.p; P.log_val = ln.log_val.p; P.log_fill = (uint32_t*)ln.log_fill.p;
+        P.log_next = meta + LM_NEXT; P.log_overflow = meta + LM_OVERFLOW; P.log_cap_chunks = plan.cap_chunks[bt.first];
+        P.log_hist = (uint32_t*)(G.bits2 ? ln.hist1.p : ln.hist.p); P.log_n_hist = n_hist; P.log_hist_shift = kTileShift + G.bits2;
+        P.log_ntx = G.ntx; P.log_nty = G.nty;
+        const unsigned long long want = (bt.second + (unsigned long long)cfg.threads - 1) / (unsigned long long)cfg.threads;
+        cfg.blocks = (int)(want < cap ? want : cap);
+        if (cfg.blocks < 1) cfg.blocks = 1;
+
+        LogReduceParams L;
+        std::memset(&L, 0, sizeof L);
+        L.log_idx = P.log_idx; L.log_val = P.log_val; L.log_fill = P.log_fill;
+        L.tmp_idx = (uint32_t*)ln.tmp_idx.p; L.tmp_val = ln.tmp_val.p;
+        L.hist1 = (uint32_t*)ln.hist1.p; L.hist = (uint32_t*)ln.hist.p;
+        L.bin_base = (uint32_t*)ln.bin_base.p; L.bin_cnt = (uint32_t*)ln.bin_cnt.p;
+        L.tile_base = (uint32_t*)ln.tile_base.p; L.tile_cnt = (uint32_t*)ln.tile_cnt.p;
+        L.cursor1 = (uint32_t*)ln.cursor1.p; L.cursor2 = (uint32_t*)ln.cursor2.p;
+        L.items2 = (uint32_t*)ln.items2.p; L.items_c = (uint32_t*)ln.items_c.p; L.items_r = (uint32_t*)ln.items_r.p;
+        L.itab = (uint32_t*)ln.itab.p;
+        L.meta = meta; L.job = (unsigned long long*)c->d_job.p; L.cap_chunks = P.log_cap_chunks;
+        L.n_tiles = G.n_tiles; L.bits2 = G.bits2;
+        L.grid = c->d_grid.p; L.n_vox = c->n_vox(); L.tally = c->tally;
+        L.nx = (uint32_t)c->nx; L.ny = (uint32_t)c->ny; L.nz = (uint32_t)c->nz; L.ntx = G.ntx; L.nty = G.nty;
+        L.flush_atomic = plan.lanes == 2 ? 1 : 0;
+
+        HIP_TRY(c, hipMemsetAsync(ln.head.p, 0, sizeof(unsigned long long), s));
+        HIP_TRY(c, hipMemsetAsync(meta, 0, LM_WORDS * 4, s));
+        HIP_TRY(c, hipMemsetAsync(ln.hist.p, 0, (size_t)G.n_tiles * (G.bits2 ? 1 : kLogGroups) * 4, s));
+        if (G.bits2) HIP_TRY(c, hipMemsetAsync(ln.hist1.p, 0, (size_t)G.nb1 * kLogGroups * 4, s));
+        HIP_TRY(c, lane_event(ln, s));
+        HIP_TRY(c, launch_walk(P, R.v, cfg, s));
+        HIP_TRY(c, lane_event(ln, s));
+        HIP_TRY(c, G.bits2 ? launch_log_scan_bins(L, s) : launch_log_scan_tiles(L, s));
+        HIP_TRY(c, lane_event(ln, s));
+        HIP_TRY(c, launch_log_part1(L, s));
+        LogReduceParams Lr = L;
+        if (G.bits2 == 0) { Lr.log_idx = L.tmp_idx; Lr.log_val = L.tmp_val; }   // one pass: tiles are final in tmp
+        else HIP_TRY(c, launch_log_part2(L, s));                                  // tile counts, their scan, pass 2
+        HIP_TRY(c, lane_event(ln, s));
+        HIP_TRY(c, launch_log_reduce(Lr, s));
+        HIP_TRY(c, lane_event(ln, s));
+        offset += bt.second;
+        (*n_batches)++;
+    }
+    if (plan.lanes == 2) {
+        HIP_TRY(c, hipEventRecord(c->lanes[1].ev_done, c->lanes[1].stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->lanes[1].ev_done, 0));
     }
     return LT_OK;
 }
@@ -304,6 +560,10 @@ int lt_create(lt_ctx** out, int device_id)
 {
     if (!out) return LT_E_INVALID;
     *out = nullptr;
+    // A launch may use two streams (lt_set_overlap).  The HIP runtime multiplexes a process's streams onto
+    // GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue are serialised.  Eight queues keep the
+    // lanes apart when torch / RCCL streams exist in the same process.  Only effective if the runtime has not started yet.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev <= 0) {
@@ -324,12 +584,16 @@ int lt_create(lt_ctx** out, int device_id)
     }
     if (e == hipSuccess) {
         size_t quarter = c->prop.totalGlobalMem / 4;
-        c->log_budget = quarter < ((size_t)64 << 30) ? quarter : ((size_t)64 << 30);
+        c->log_budget = c->default_log_budget = quarter < ((size_t)64 << 30) ? quarter : ((size_t)64 << 30);
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->lanes[1].stream, hipStreamNonBlocking);
+    c->lanes[0].stream = c->stream;
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    for (int k = 0; k < 6 && e == hipSuccess; k++) e = hipEventCreate(&c->evs[k]);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->lanes[k].ev_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = c->d_job.ensure(2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = c->d_counters.ensure(sizeof(DevCounters));
     if (e == hipSuccess) e = c->d_head.ensure(sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), c->stream);
@@ -352,12 +616,17 @@ int lt_destroy(lt_ctx* c)
     c->d_scratch_in.release(); c->d_scratch_out.release(); c->d_scratch_aux.release();
     c->d_mats.release(); c->d_lights.release(); c->d_r0.release(); c->d_r1.release(); c->d_lc.release();
     c->d_img.release(); c->d_xy.release(); c->d_vtx.release(); c->d_vcnt.release(); c->d_clear.release();
-    c->d_log_idx.release(); c->d_log_val.release(); c->d_tmp_idx.release(); c->d_tmp_val.release(); c->d_log_fill.release();
-    c->d_log_meta.release(); c->d_hist.release(); c->d_tile_base.release(); c->d_cursor1.release(); c->d_cursor2.release();
-    c->d_items2.release(); c->d_items_r.release();
+    c->d_job.release();
+    if (c->lanes[1].stream) (void)hipStreamSynchronize(c->lanes[1].stream);
+    for (int k = 0; k < 2; k++) {
+        c->lanes[k].release_all();
+        for (hipEvent_t ev : c->lanes[k].evs) (void)hipEventDestroy(ev);
+        if (c->lanes[k].ev_done) (void)hipEventDestroy(c->lanes[k].ev_done);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    for (int k = 0; k < 6; k++) if (c->evs[k]) (void)hipEventDestroy(c->evs[k]);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->lanes[1].stream) (void)hipStreamDestroy(c->lanes[1].stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LT_OK;
@@ -373,7 +642,7 @@ int lt_set_media(lt_ctx* c, const lt_medium* media, int n)
             return c->fail(LT_E_INVALID, "lt_set_media: medium %d out of range (mu_a,mu_s >= 0, |g| < 1, n > 0)", i);
     }
     c->media.assign(media, media + n);
-    c->rec_per_photon = 0.0;
+    c->scene_changed();
     c->tables_dirty = true;
     return LT_OK;
 }
@@ -393,6 +662,7 @@ int lt_set_layers(lt_ctx* c, const double* z_bounds, const int32_t* medium_idx, 
     c->layer_medium.assign(medium_idx, medium_idx + n);
     c->n_above = n_above; c->n_below = n_below;
     c->have_layers = true; c->have_mesh = false;
+    c->scene_changed();
     c->tables_dirty = true;
     return LT_OK;
 }
@@ -419,6 +689,7 @@ int lt_set_mesh(lt_ctx* c, const double* verts, const int32_t* med_front, const 
     c->nodes.swap(nn);
     c->have_mesh = true; c->have_layers = false;
     c->surf_mats.clear();
+    c->scene_changed();
     c->tables_dirty = true;
     return LT_OK;
 }
@@ -436,6 +707,7 @@ int lt_set_grid(lt_ctx* c, int nx, int ny, int nz, const double origin[3], const
     for (int k = 0; k < 3; k++) { c->origin[k] = origin[k]; c->voxel[k] = voxel[k]; }
     HIP_TRY(c, c->d_grid.ensure(c->n_vox() * c->grid_elem()));
     c->have_grid = true;
+    c->scene_changed();
     return lt_zero_tally(c);
 }
 
@@ -450,6 +722,7 @@ int lt_set_source(lt_ctx* c, int type, const double pos[3], const double dir[3],
     for (int k = 0; k < 3; k++) { c->src_pos[k] = pos[k]; c->src_dir[k] = dir[k] / l; }
     for (int k = 0; k < 6; k++) c->src_extra[k] = extra ? extra[k] : 0.0;
     c->have_source = true;
+    c->scene_changed();
     return LT_OK;
 }
 
@@ -551,7 +824,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         HIP_TRY(c, c->d_vcnt.ensure((size_t)n_photons * sizeof(uint32_t)));
         HIP_TRY(c, hipMemsetAsync(c->d_vcnt.p, 0, (size_t)n_photons * sizeof(uint32_t), c->stream));
         P.vertices = (lt_vertex*)c->d_vtx.p; P.vertex_counts = (uint32_t*)c->d_vcnt.p; P.max_vertices = c->max_vertices;
-        c->captured_photons = n_photons;
+        c->captured_photons = n_photons; c->captured_max_vertices = c->max_vertices;
     }
 
     LaunchCfg cfg;
@@ -573,152 +846,65 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     if (cfg.blocks < 1) cfg.blocks = 1;
 
     // ---- log-structured tally: walk -> deposit log -> partition by grid tile -> LDS tile reduce, in batches
-    const uint32_t ntx = ((uint32_t)c->nx + 31u) >> kTileBX, nty = ((uint32_t)c->ny + 31u) >> kTileBY,
-                   ntz = ((uint32_t)c->nz + 15u) >> kTileBZ;
-    const uint32_t n_tiles = ntx * nty * ntz;   // 32 x 32 x 16-voxel blocks
-    const uint32_t n_tiles_pre = (uint32_t)((c->n_vox() + kTileSize - 1) >> kTileShift);
-    (void)n_tiles_pre;
     // auto: slab walks and f32 mesh walks are paced by the atomic unit -> log (C4, f32: 43 ms log vs 60 ms atomic);
     // the f64 mesh walk's BVH arithmetic hides the atomics, so the log passes would only add time (58 vs 59 ms)
     const int mode = c->tally_mode == 2 ? ((c->have_mesh && !v.f32) ? 0 : 1) : c->tally_mode;
     { int rc3 = collect_log_stats(c); if (rc3) return rc3; }   // stats of the previous launch size this one
-    bool use_log = mode == 1 && !v.table && c->max_vertices == 0 && n_tiles <= 16384 && !std::getenv("LT_DIAG_NO_TALLY");
+    LogGeom G = log_geom(c);
+    bool use_log = mode == 1 && !v.table && c->max_vertices == 0 && G.n_tiles <= kMaxLogTiles && !std::getenv("LT_DIAG_NO_TALLY");
     if (use_log) {
-        const size_t rec_bytes = 4 + c->grid_elem();
-        size_t budget_records = c->log_budget / (2 * rec_bytes);
-        if (budget_records > 0xFFF00000ull) budget_records = 0xFFF00000ull;   // 32-bit record offsets
-        if (budget_records < 64 * (size_t)kLogChunk) return c->fail(LT_E_INVALID, "lt_launch: log budget too small (%zu bytes)", c->log_budget);
-        // size the log to the job: measured records per photon when known, else a pilot-sized log
-        // (a log that turns out too small only diverts the excess deposits to atomics)
-        auto size_log = [&](uint64_t photons_left) -> size_t {
-            // no measurement yet: assume 200 records per photon (tissue-like media give 100-300); a wrong guess is
-            // corrected after the first batch and an undersized log only diverts the excess deposits to atomics
-            const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 200.0;
-            double need = 1.25 * rate * (double)photons_left + 1048576.0;
-            size_t r = need < (double)budget_records ? (size_t)need : budget_records;
-            return ((r + kLogChunk - 1) / kLogChunk) * kLogChunk;
-        };
-        size_t cap_records = size_log(n_photons);
-        uint32_t cap_chunks = (uint32_t)(cap_records / kLogChunk);
-        auto ensure_log = [&]() -> hipError_t {
-            hipError_t e;
-            if (c->log_alloc_elem != (int)c->grid_elem()) c->log_alloc_records = 0;
-            if (cap_records <= c->log_alloc_records) {   // use everything that is already there
-                cap_records = c->log_alloc_records; cap_chunks = (uint32_t)(cap_records / kLogChunk);
-                return hipSuccess;
-            }
-            // grow geometrically so that run-to-run jitter of the record rate does not re-allocate tens of GB
-            size_t grown = cap_records + cap_records / 8;
-            if (grown > budget_records) grown = budget_records;
-            cap_records = (grown / kLogChunk) * kLogChunk; cap_chunks = (uint32_t)(cap_records / kLogChunk);
-            c->log_alloc_records = cap_records; c->log_alloc_elem = (int)c->grid_elem();
-            if ((e = c->d_log_idx.ensure(cap_records * 4)) != hipSuccess) return e;
-            if ((e = c->d_tmp_idx.ensure(cap_records * 4)) != hipSuccess) return e;
-            if ((e = c->d_log_val.ensure(cap_records * c->grid_elem())) != hipSuccess) return e;
-            if ((e = c->d_tmp_val.ensure(cap_records * c->grid_elem())) != hipSuccess) return e;
-            return c->d_log_fill.ensure((size_t)cap_chunks * 4);
-        };
-        if (ensure_log() != hipSuccess) {
-            // not enough free HBM for the log (other contexts, a huge grid): this launch deposits with atomics instead
-            (void)hipGetLastError();
-            c->d_log_idx.release(); c->d_tmp_idx.release(); c->d_log_val.release(); c->d_tmp_val.release(); c->d_log_fill.release();
-            c->log_alloc_records = 0;
-            use_log = false;
-        }
-    }
-    if (use_log) {
-        // batches use what is allocated; later batches shrink or grow with the measured record rate
-        const size_t cap_records = c->log_alloc_records;
-        const uint32_t cap_chunks = (uint32_t)(cap_records / kLogChunk);
-        HIP_TRY(c, c->d_log_meta.ensure(64));
-        uint32_t bits2 = 1; while ((1u << (2 * bits2)) < n_tiles) bits2++;
-        // grids of <= 1024 tiles (256^3): ONE partition pass straight to tiles.  Records cluster in the few dozen
-        // tiles around the source, so the per-tile runs of a 4096-record work item stay long enough to coalesce.
-        if (n_tiles <= 1024) bits2 = 0;
-        if (const char* e = std::getenv("LT_LOG_BITS2")) bits2 = (uint32_t)std::atoi(e);
-        const uint32_t nb1 = (n_tiles + (1u << bits2) - 1) >> bits2;
-        HIP_TRY(c, c->d_hist.ensure((size_t)n_tiles * 4)); HIP_TRY(c, c->d_tile_base.ensure((size_t)(n_tiles + 1) * 4));
-        HIP_TRY(c, c->d_cursor1.ensure((size_t)nb1 * 4)); HIP_TRY(c, c->d_cursor2.ensure((size_t)n_tiles * 4));
-        HIP_TRY(c, c->d_items2.ensure((size_t)(nb1 + 1) * 4)); HIP_TRY(c, c->d_items_r.ensure((size_t)(n_tiles + 1) * 4));
-        uint32_t* meta = (uint32_t*)c->d_log_meta.p;   // [0] next chunk, [2..3] totals
-        P.log_idx = (uint32_t*)c->d_log_idx.p; P.log_val = c->d_log_val.p; P.log_fill = (uint32_t*)c->d_log_fill.p;
-        P.log_next = meta; P.log_cap_chunks = cap_chunks;
-        P.log_hist = (uint32_t*)c->d_hist.p; P.log_n_tiles = n_tiles; P.log_ntx = ntx; P.log_nty = nty;
-        cfg.lds_bytes = walk_lds_bytes(v, P.n_media, P.n_layers, P.n_tris, P.n_nodes, n_tiles);
-        {
-            const int res2 = walk_max_blocks_per_cu(v, cfg.threads, cfg.lds_bytes);
-            if (res2 <= 0) return c->fail(LT_E_HIP, "lt_launch: log-mode kernel not resident");
-            const int pc = c->blocks_per_cu > 0 ? c->blocks_per_cu : res2;
-            cap = (unsigned long long)pc * (unsigned long long)c->prop.multiProcessorCount;
-        }
-        LogReduceParams L;
-        std::memset(&L, 0, sizeof L);
-        L.log_idx = P.log_idx; L.log_val = P.log_val; L.log_fill = P.log_fill;
-        L.tmp_idx = (uint32_t*)c->d_tmp_idx.p; L.tmp_val = c->d_tmp_val.p;
-        L.hist = (uint32_t*)c->d_hist.p; L.tile_base = (uint32_t*)c->d_tile_base.p;
-        L.cursor1 = (uint32_t*)c->d_cursor1.p; L.cursor2 = (uint32_t*)c->d_cursor2.p; L.items2 = (uint32_t*)c->d_items2.p; L.items_r = (uint32_t*)c->d_items_r.p;
-        L.totals = meta + 2; L.n_tiles = n_tiles; L.bits2 = bits2;
-        L.grid = c->d_grid.p; L.n_vox = c->n_vox(); L.tally = c->tally;
-        L.nx = (uint32_t)c->nx; L.ny = (uint32_t)c->ny; L.nz = (uint32_t)c->nz; L.ntx = ntx; L.nty = nty;
-
-        L.chunks_used = meta; L.cap_chunks = cap_chunks; L.work = meta + 5;
-        // Everything below is enqueued without a host read-back: item counts stay in device memory and the
-        // partition / reduce kernels are persistent work loops.  Statistics of the LAST batch (records, overflow)
-        // are collected lazily (collect_log_stats) and steer the batch size of the next launch.
-        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        LogRun R;
+        R.c = c; R.P = P; R.v = v; R.cfg = cfg; R.G = G;
+        c->stages_valid = false;
+        c->lanes[0].ev_used = c->lanes[1].ev_used = 0;
+        HIP_TRY(c, hipMemsetAsync(c->d_job.p, 0, 2 * sizeof(unsigned long long), c->stream));
         uint64_t done = 0;
-        const bool diag = std::getenv("LT_LOG_TIMING") != nullptr;   // prints per-stage device times (syncs per batch)
-        double stage[4] = {0, 0, 0, 0};
         int n_batches = 0;
-        while (done < n_photons) {
-            uint64_t batch = n_photons - done;
-            {
-                const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 200.0;
-                const double fit = 0.8 * (double)cap_records / rate;
-                if ((double)batch > fit) batch = fit < 4096.0 ? 4096 : (uint64_t)fit;
+        // No record rate known for this scene yet: trace a small pilot batch first and read its rate back (a few ms,
+        // once per scene), so that the logs and batches of the rest are sized from a measurement, not from a guess.
+        if (c->rec_per_photon <= 0.0 && n_photons > kPilotPhotons) {
+            LogPlan pilot;
+            rc = plan_log(c, kPilotPhotons, 1, &pilot);
+            if (rc == LT_OK) rc = run_log_plan(R, pilot, photon_offset, &n_batches);
+            if (rc == LT_E_NOMEM) { use_log = false; rc = LT_OK; }
+            else if (rc) return rc;
+            else {
+                c->log_stats_pending = true; c->pending_photons = kPilotPhotons; c->auto_pending = -1;
+                if ((rc = collect_log_stats(c))) return rc;
+                done = kPilotPhotons;
             }
-            P.n_photons = batch; P.photon_offset = photon_offset + done;
-            want = (batch + (unsigned long long)cfg.threads - 1) / (unsigned long long)cfg.threads;
-            cfg.blocks = (int)(want < cap ? want : cap);
-            if (cfg.blocks < 1) cfg.blocks = 1;
-            HIP_TRY(c, hipMemsetAsync(c->d_head.p, 0, sizeof(unsigned long long), c->stream));
-            HIP_TRY(c, hipMemsetAsync(meta, 0, 32, c->stream));
-            HIP_TRY(c, hipMemsetAsync(c->d_hist.p, 0, (size_t)n_tiles * 4, c->stream));
-            HIP_TRY(c, hipEventRecord(c->evs[0], c->stream));
-            HIP_TRY(c, launch_walk(P, v, cfg, c->stream));
-            HIP_TRY(c, hipEventRecord(c->evs[1], c->stream));
-            HIP_TRY(c, launch_log_scan(L, c->stream));
-            HIP_TRY(c, hipEventRecord(c->evs[2], c->stream));
-            HIP_TRY(c, launch_log_part1(L, c->stream));
-            LogReduceParams Lr = L;
-            if (bits2 == 0) { Lr.log_idx = L.tmp_idx; Lr.log_val = L.tmp_val; }   // single pass: tiles are final in tmp
-            else HIP_TRY(c, launch_log_part2(L, c->stream));
-            HIP_TRY(c, hipEventRecord(c->evs[4], c->stream));
-            HIP_TRY(c, launch_log_reduce(Lr, c->stream));
-            HIP_TRY(c, hipEventRecord(c->evs[5], c->stream));
-            c->log_stats_pending = true; c->pending_batch = batch; c->pending_cap_chunks = cap_chunks;
-            if (diag) {
-                int rc2 = collect_log_stats(c);
-                if (rc2) return rc2;
-                float f;
-                (void)hipEventElapsedTime(&f, c->evs[0], c->evs[1]); stage[0] += f;
-                (void)hipEventElapsedTime(&f, c->evs[1], c->evs[2]); stage[1] += f;
-                (void)hipEventElapsedTime(&f, c->evs[2], c->evs[4]); stage[2] += f;
-                (void)hipEventElapsedTime(&f, c->evs[4], c->evs[5]); stage[3] += f;
-                std::fprintf(stderr, "[lt log] batch %d: %llu photons, %llu records (%.1f / photon)%s\n", n_batches,
-                             (unsigned long long)batch, (unsigned long long)c->last_records,
-                             (double)c->last_records / (double)batch, c->last_overflow ? ", LOG OVERFLOW -> atomics" : "");
-            }
-            n_batches++;
-            done += batch;
         }
-        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-        c->stages_valid = true; c->last_batches = (uint64_t)n_batches;
-        if (diag)
-            std::fprintf(stderr, "[lt log] stages ms: walk %.2f scan %.2f partition %.2f reduce %.2f\n", stage[0], stage[1],
-                         stage[2], stage[3]);
-        c->timed = true;
-        return LT_OK;
+        if (use_log) {
+            int lanes = choose_lanes(c, n_photons - done);
+            LogPlan plan;
+            rc = plan_log(c, n_photons - done, lanes, &plan);
+            if (rc == LT_E_NOMEM && lanes == 2) { lanes = 1; rc = plan_log(c, n_photons - done, 1, &plan); }
+            if (rc == LT_E_NOMEM) { use_log = false; rc = LT_OK; }
+            else if (rc) return rc;
+            else {
+                HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+                if ((rc = run_log_plan(R, plan, photon_offset + done, &n_batches))) return rc;
+                HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+                c->stages_valid = true; c->last_batches = (uint64_t)n_batches; c->last_lanes = plan.lanes;
+                c->log_stats_pending = true; c->pending_photons = n_photons;   // the job counters hold the pilot's records too
+                if (c->auto_pending >= 0 && done > 0) c->auto_pending = -1;     // (first launch of a scene: not a clean measurement)
+                c->timed = true;
+                if (std::getenv("LT_LOG_TIMING")) {   // diagnostic: per-stage device times of this launch (synchronises)
+                    double ms[4]; uint64_t rec = 0, bat = 0;
+                    if (lt_last_log_stages(c, ms, &rec, &bat) == LT_OK)
+                        std::fprintf(stderr, "[lt log] %llu photons, %d lane(s), %llu batches, %llu records (%.1f / photon), %llu to atomics; "
+                                     "stage sums ms: walk %.2f scan %.2f partition %.2f reduce %.2f\n", (unsigned long long)n_photons,
+                                     plan.lanes, (unsigned long long)bat, (unsigned long long)rec, (double)rec / (double)n_photons,
+                                     (unsigned long long)c->last_overflow, ms[0], ms[1], ms[2], ms[3]);
+                }
+                return LT_OK;
+            }
+        }
+        // not enough free HBM for a log (other contexts, a huge grid): the rest of this launch deposits with atomics
+        P.n_photons = n_photons - done; P.photon_offset = photon_offset + done;
+        want = (P.n_photons + (unsigned long long)cfg.threads - 1) / (unsigned long long)cfg.threads;
+        cfg.blocks = (int)(want < cap ? want : cap);
+        if (cfg.blocks < 1) cfg.blocks = 1;
     }
 
     c->stages_valid = false;
@@ -735,19 +921,11 @@ int lt_reserve_log(lt_ctx* c, uint64_t n_photons)
     CHECK_CTX(c);
     if (!c->have_grid) return c->fail(LT_E_STATE, "lt_reserve_log: lt_set_grid first");
     BIND(c);
-    const size_t rec_bytes = 4 + c->grid_elem();
-    size_t budget_records = c->log_budget / (2 * rec_bytes);
-    if (budget_records > 0xFFF00000ull) budget_records = 0xFFF00000ull;
-    const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 200.0;
-    double need = 1.25 * rate * (double)n_photons + 1048576.0;
-    size_t r = need < (double)budget_records ? (size_t)need : budget_records;
-    r = ((r + kLogChunk - 1) / kLogChunk) * kLogChunk;
-    if (c->log_alloc_elem == (int)c->grid_elem() && r <= c->log_alloc_records) return LT_OK;
-    HIP_TRY(c, c->d_log_idx.ensure(r * 4)); HIP_TRY(c, c->d_tmp_idx.ensure(r * 4));
-    HIP_TRY(c, c->d_log_val.ensure(r * c->grid_elem())); HIP_TRY(c, c->d_tmp_val.ensure(r * c->grid_elem()));
-    HIP_TRY(c, c->d_log_fill.ensure((r / kLogChunk) * 4));
-    c->log_alloc_records = r; c->log_alloc_elem = (int)c->grid_elem();
-    return LT_OK;
+    LogPlan plan;
+    int lanes = c->overlap_mode == 1 ? 1 : ((c->overlap_mode == 2 || (c->blocks_per_cu == 0 && n_photons >= kOverlapMinPhotons)) ? 2 : 1);
+    int rc = plan_log(c, n_photons, lanes, &plan);
+    if (rc == LT_E_NOMEM) return c->fail(LT_E_NOMEM, "lt_reserve_log: not enough device memory for the deposit log");
+    return rc;
 }
 
 int lt_set_tally_mode(lt_ctx* c, int mode, uint64_t log_bytes)
@@ -755,8 +933,16 @@ int lt_set_tally_mode(lt_ctx* c, int mode, uint64_t log_bytes)
     CHECK_CTX(c);
     if (mode < 0 || mode > 2) return c->fail(LT_E_INVALID, "lt_set_tally_mode: mode must be LT_MODE_ATOMIC, LT_MODE_LOG or LT_MODE_AUTO");
     c->tally_mode = mode;
-    if (log_bytes) c->log_budget = (size_t)log_bytes;
-    c->rec_per_photon = 0.0;
+    c->log_budget = log_bytes ? (size_t)log_bytes : c->default_log_budget;
+    return LT_OK;
+}
+
+int lt_set_overlap(lt_ctx* c, int lanes)
+{
+    CHECK_CTX(c);
+    if (lanes < 0 || lanes > 2) return c->fail(LT_E_INVALID, "lt_set_overlap: 0 (auto), 1 or 2");
+    c->overlap_mode = lanes;
+    c->auto_ms_per_photon[0] = c->auto_ms_per_photon[1] = 0.0; c->auto_pending = -1;
     return LT_OK;
 }
 
@@ -787,15 +973,35 @@ int lt_last_log_stages(lt_ctx* c, double ms_out[4], uint64_t* records, uint64_t*
     if (!ms_out) return c->fail(LT_E_INVALID, "lt_last_log_stages: null output");
     if (!c->stages_valid) return c->fail(LT_E_STATE, "lt_last_log_stages: the last launch did not use the log tally");
     BIND(c);
-    HIP_TRY(c, hipEventSynchronize(c->evs[5]));
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
     { int rc3 = collect_log_stats(c); if (rc3) return rc3; }
-    float f;
-    HIP_TRY(c, hipEventElapsedTime(&f, c->evs[0], c->evs[1])); ms_out[0] = f;   // walk
-    HIP_TRY(c, hipEventElapsedTime(&f, c->evs[1], c->evs[2])); ms_out[1] = f;   // counts readback + scan
-    HIP_TRY(c, hipEventElapsedTime(&f, c->evs[2], c->evs[4])); ms_out[2] = f;   // partition pass(es)
-    HIP_TRY(c, hipEventElapsedTime(&f, c->evs[4], c->evs[5])); ms_out[3] = f;   // tile reduce
+    for (int k = 0; k < 4; k++) ms_out[k] = 0.0;
+    for (int l = 0; l < 2; l++) {
+        const LogLane& ln = c->lanes[l];
+        for (size_t b = 0; b + 5 <= ln.ev_used; b += 5) {
+            float f;
+            HIP_TRY(c, hipEventElapsedTime(&f, ln.evs[b], ln.evs[b + 1])); ms_out[0] += f;       // walk
+            HIP_TRY(c, hipEventElapsedTime(&f, ln.evs[b + 1], ln.evs[b + 2])); ms_out[1] += f;   // scan
+            HIP_TRY(c, hipEventElapsedTime(&f, ln.evs[b + 2], ln.evs[b + 3])); ms_out[2] += f;   // partition pass(es)
+            HIP_TRY(c, hipEventElapsedTime(&f, ln.evs[b + 3], ln.evs[b + 4])); ms_out[3] += f;   // tile reduce
+        }
+    }
     if (records) *records = c->last_records;
     if (batches) *batches = c->last_batches;
+    return LT_OK;
+}
+
+int lt_last_log_info(lt_ctx* c, uint64_t* records, uint64_t* overflow_records, uint64_t* batches, int* lanes)
+{
+    CHECK_CTX(c);
+    if (!c->stages_valid) return c->fail(LT_E_STATE, "lt_last_log_info: the last launch did not use the log tally");
+    BIND(c);
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    { int rc3 = collect_log_stats(c); if (rc3) return rc3; }
+    if (records) *records = c->last_records;
+    if (overflow_records) *overflow_records = c->last_overflow;
+    if (batches) *batches = c->last_batches;
+    if (lanes) *lanes = c->last_lanes;
     return LT_OK;
 }
 
@@ -1031,12 +1237,16 @@ int lt_set_vertex_capture(lt_ctx* c, uint32_t max_vertices_per_photon)
 int lt_read_vertices(lt_ctx* c, lt_vertex* vertices_out, uint32_t* counts_out, uint64_t n_photons)
 {
     CHECK_CTX(c);
-    if (c->captured_photons == 0 || c->max_vertices == 0) return c->fail(LT_E_STATE, "lt_read_vertices: the last launch captured nothing");
+    // sizes come from the capturing launch, not from a later lt_set_vertex_capture
+    if (c->captured_photons == 0 || c->captured_max_vertices == 0) return c->fail(LT_E_STATE, "lt_read_vertices: the last launch captured nothing");
     if (!vertices_out || !counts_out || n_photons != c->captured_photons)
         return c->fail(LT_E_INVALID, "lt_read_vertices: expected buffers for %llu photons", (unsigned long long)c->captured_photons);
+    if (c->max_vertices != c->captured_max_vertices)
+        return c->fail(LT_E_STATE, "lt_read_vertices: lt_set_vertex_capture changed (%u -> %u) since the capturing launch",
+                       c->captured_max_vertices, c->max_vertices);
     BIND(c);
     HIP_TRY(c, hipMemcpyAsync(counts_out, c->d_vcnt.p, (size_t)n_photons * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(vertices_out, c->d_vtx.p, (size_t)n_photons * c->max_vertices * sizeof(lt_vertex), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(vertices_out, c->d_vtx.p, (size_t)n_photons * c->captured_max_vertices * sizeof(lt_vertex), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return LT_OK;
 }

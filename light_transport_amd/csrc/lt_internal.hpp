@@ -45,6 +45,14 @@ constexpr uint32_t kTileSize = 1u << kTileShift;
 // (tz * nty + ty) * ntx + tx.  3-D blocks follow the compact photon cloud, so far fewer tiles are active than with
 // slabs of consecutive linear indices and the partition pass writes longer contiguous runs.
 constexpr uint32_t kTileBX = 5, kTileBY = 5, kTileBZ = 4;
+// The first partition pass claims output space with one returning global atomic per (work item, non-empty digit).
+// Records cluster in a few dozen tiles, so EVERY work item hits the same hot cursors, and one address sustains only
+// ~90 atomics per microsecond (MI355X_MICROARCH "dequeue" / "fanin").  Walk workgroups therefore belong to one of
+// kLogGroups groups (blockIdx % kLogGroups): each group has its own histogram column and its own cursor per digit,
+// a chunk remembers its group (top byte of its log_fill word), and a digit's region is the groups' sub-regions back
+// to back.
+constexpr uint32_t kLogGroups = 16;
+constexpr uint32_t kFillMask = 0x00ffffffu;
 constexpr int kMaxLayers = 64;
 
 struct WalkParams {
@@ -75,11 +83,14 @@ struct WalkParams {
     // reduced into the grid by the partition / tile-reduce kernels
     uint32_t* log_idx;    // [log_cap_chunks * kLogChunk] voxel index
     void* log_val;        // [log_cap_chunks * kLogChunk] value in the tally's type
-    uint32_t* log_fill;   // [log_cap_chunks] valid records per chunk
+    uint32_t* log_fill;   // [log_cap_chunks] valid records per chunk | group << 24
     uint32_t* log_next;   // next free chunk
     uint32_t log_cap_chunks;
-    uint32_t* log_hist;   // [log_n_tiles] records per grid tile, accumulated by the walk (LDS histogram per workgroup)
-    uint32_t log_n_tiles, log_ntx, log_nty;
+    uint32_t* log_hist;   // [log_n_hist][kLogGroups] records per partition bin and group, accumulated by the walk (LDS histogram per workgroup):
+                          // bin = tile id >> (log_hist_shift - kTileShift): the tile itself for grids of <= 1024 tiles,
+                          // the level-1 digit of the two-pass partition otherwise (<= 128 bins: 512 B of LDS)
+    uint32_t log_n_hist, log_hist_shift, log_ntx, log_nty;
+    uint32_t* log_overflow;   // [1] records that found the log full and went to the grid as global atomics
     // clearance grid (mesh scenes; null = off): conservative lower bound of the distance from any point of a cell
     // to any triangle -- a hop shorter than that cannot hit, so the BVH query is skipped
     const float* clear;
@@ -131,29 +142,50 @@ hipError_t launch_build_clearance(const void* tris_f64, int n_tris, float* clear
                                   const double org[3], const double cell[3], hipStream_t s);
 hipError_t launch_render_surface(const RenderParams& P, hipStream_t s);
 
+// Per-batch bookkeeping words of the log pipeline (one u32 array per lane, zeroed before every batch).
+enum { LM_NEXT = 0,        // chunks the walk claimed (may exceed the capacity when the log overflowed)
+       LM_OVERFLOW,        // records that went to the grid as atomics because the log was full
+       LM_RECORDS,         // totals: records in the log
+       LM_ITEMS2,          //         pass-2 work items
+       LM_ITEMS_R,         //         reduce work items
+       LM_SLICE,           //         records per reduce work item (chosen by the scan from the record count)
+       LM_ITEMS_C,         //         k_log_count2 work items (two-pass form)
+       LM_WORK,            // work-item counter of the reduce (the other passes stride the grid over equal-sized items)
+       LM_WORDS = 12 };
+// tile / bin regions start at multiples of these record counts so that the wide (16-byte) loads of the next pass are
+// aligned; the gaps are never read (a region's length comes from the histogram), the buffers carry the slack
+constexpr uint32_t kTileAlign = 8, kBinAlign = 4;
+
 // log-structured tally pipeline (all on stream s)
 struct LogReduceParams {
-    const uint32_t* log_idx; const void* log_val; const uint32_t* log_fill; uint32_t n_chunks;   // walk output
+    const uint32_t* log_idx; const void* log_val; const uint32_t* log_fill;   // walk output
     uint32_t* tmp_idx; void* tmp_val;          // ping-pong buffers, same capacity as the log
-    uint32_t* hist;                            // [n_tiles]
-    uint32_t* tile_base;                       // [n_tiles + 1]
-    uint32_t* cursor1;                         // [nb1]
+    uint32_t* hist1;                           // [nb1][kLogGroups] records per level-1 bin and group (two-pass form: the walk's histogram)
+    uint32_t* hist;                            // records per tile: one-pass form [n_tiles][kLogGroups], the walk's histogram;
+                                               //                   two-pass form [n_tiles], counted from pass 1's output
+    uint32_t* bin_base; uint32_t* bin_cnt;     // [nb1 + 1] / [nb1] where pass 1 puts each level-1 bin, records in it
+    uint32_t* tile_base; uint32_t* tile_cnt;   // [n_tiles + 1] / [n_tiles] where the final pass puts each tile, records in it
+    uint32_t* cursor1;                         // [nb1][kLogGroups] (one-pass form: [n_tiles][kLogGroups])
     uint32_t* cursor2;                         // [n_tiles]
     uint32_t* items2;                          // [nb1 + 1] prefix of pass-2 work items per level-1 bin
+    uint32_t* items_c;                         // [nb1 + 1] prefix of tile-count work items per level-1 bin
+    uint32_t* itab;                            // [pass-2 items][4] descriptor of every pass-2 work item (k_log_items2)
     uint32_t* items_r;                         // [n_tiles + 1] prefix of reduce work items per tile
-    uint32_t* totals;                          // [3]: total records, pass-2 items, reduce items
-    const uint32_t* chunks_used;               // [1]: chunks the walk claimed (may exceed cap_chunks on overflow)
+    uint32_t* meta;                            // [LM_WORDS]
+    unsigned long long* job;                   // [2] records / overflowed records of the whole launch (all batches)
     uint32_t cap_chunks;
-    uint32_t* work;                            // [3]: work-item counters of part1, part2, reduce (zeroed per batch)
-    uint32_t n_tiles, bits2;                   // level-2 digit width; level-1 bins = ceil(n_tiles >> bits2)
+    uint32_t n_tiles, bits2;                   // level-2 digit width; level-1 bins = ceil(n_tiles >> bits2); 0 = one pass
     void* grid; size_t n_vox; int tally;
     uint32_t nx, ny, nz, ntx, nty;             // grid shape and tile counts along x, y (tiled record index)
+    int flush_atomic;                          // every tile adds to the grid with atomics (another lane of the same
+                                               // launch may be updating it at the same time)
 };
-hipError_t launch_log_hist(const LogReduceParams& L, hipStream_t s);
-hipError_t launch_log_scan(const LogReduceParams& L, hipStream_t s);
+hipError_t launch_log_scan_bins(const LogReduceParams& L, hipStream_t s);
+hipError_t launch_log_scan_tiles(const LogReduceParams& L, hipStream_t s);
 hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s);
 hipError_t launch_log_part2(const LogReduceParams& L, hipStream_t s);
 hipError_t launch_log_reduce(const LogReduceParams& L, hipStream_t s);
+uint32_t log_part_item();   // records per partition work item (the log capacity is a multiple of it)
 
 hipError_t launch_intersect_rays(const void* tris, const void* nodes, int n_tris, int n_nodes,
                                  const double* o, const double* d, const double* tmax, size_t n,

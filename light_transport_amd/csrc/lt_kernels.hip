@@ -547,7 +547,7 @@ LT_DEV void record_vertex(const WalkParams& P, unsigned long long rel, unsigned&
 
 // One deposit record per lane (or none) leaves the lane's run-length accumulator.  Atomic mode: a no-return
 // global atomic.  Log mode: the wave's records are compacted by ballot rank and appended, coalesced, to the wave's
-// current log chunk (SoA: voxel index, value); a chunk is claimed with one returning atomic per 4096 records.
+// current log chunk (SoA: voxel index, value); a chunk is claimed with one returning atomic per kLogChunk records.
 // If the log is exhausted the wave falls back to atomics, so a too-small log costs speed, never correctness.
 template <int TALLY>
 LT_DEV void emit_deposit(const WalkParams& P, bool has, unsigned idx, typename TallyT<TALLY>::type val,
@@ -563,7 +563,8 @@ LT_DEV void emit_deposit(const WalkParams& P, bool has, unsigned idx, typename T
     const unsigned cnt = (unsigned)__popcll(m);
     if (lg_end - lg_cur < cnt) {
         const int lane = threadIdx.x & 63;
-        if (lg_chunk != 0xffffffffu && lane == 0) P.log_fill[lg_chunk] = lg_cur - lg_chunk * kLogChunk;
+        if (lg_chunk != 0xffffffffu && lane == 0)
+            P.log_fill[lg_chunk] = (lg_cur - lg_chunk * kLogChunk) | ((blockIdx.x & (kLogGroups - 1)) << 24);
         unsigned c = 0;
         if (lane == 0) c = __hip_atomic_fetch_add(P.log_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c = __builtin_amdgcn_readfirstlane(c);
@@ -571,6 +572,7 @@ LT_DEV void emit_deposit(const WalkParams& P, bool has, unsigned idx, typename T
         else { lg_chunk = 0xffffffffu; lg_cur = lg_end = 0; }
     }
     if (lg_chunk == 0xffffffffu) {  // log exhausted: back to the linear voxel index and a global atomic
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(P.log_overflow, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (has) {
             const unsigned tile = idx >> kTileShift, tx = tile % P.log_ntx, ty = (tile / P.log_ntx) % P.log_nty,
                            tz = tile / (P.log_ntx * P.log_nty);
@@ -584,7 +586,7 @@ LT_DEV void emit_deposit(const WalkParams& P, bool has, unsigned idx, typename T
         const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         P.log_idx[lg_cur + rank] = idx;
         reinterpret_cast<TV*>(P.log_val)[lg_cur + rank] = val;
-        atomicAdd(&s_hist[idx >> kTileShift], 1u);   // tile histogram for the partition pass, kept in LDS
+        atomicAdd(&s_hist[idx >> P.log_hist_shift], 1u);   // histogram of the first partition pass's bins, kept in LDS
     }
     lg_cur += cnt;
 }

@@ -4,15 +4,23 @@
 // (~16e9 requests/s) while its arithmetic alone would sustain 4x that.  MI355X has 288 GB of
 // HBM at ~6 TB/s of streaming bandwidth, so the deposits are instead WRITTEN as a coalesced log
 // (lt_kernels.hip: emit_deposit) and reduced here with streaming passes only:
-//   (walk)       records per grid tile, LDS histogram (tile = 32 x 32 x 16 voxels = one LDS-sized block of the grid)
-//   k_log_scan   exclusive prefix -> where every tile's records will live; level-1 / level-2 cursors
-//   k_log_part   LSD-free two-level radix partition by tile id (pass 1: high digit, pass 2: low digit);
-//                a workgroup sorts 4096 records by digit in LDS and writes each digit's run contiguously
-//   k_log_reduce one workgroup per tile: LDS adds of all its records, then ONE plain read-add-write per
-//                touched voxel (the tile has exactly one owner, so no global atomics at all)
-// Integer (u64 fixed-point) tallies stay bit-identical to the atomic path; float tallies differ by summation
-// order only, as they already do between two atomic runs.
+//   (walk)            records per partition bin, LDS histogram (<= 4 KiB per workgroup)
+//   k_log_scan_*      exclusive prefixes -> where every bin / tile's records will live, work-item tables
+//   k_log_part        counting sort of 4096-record work items by tile id in LDS; every digit's run leaves as one
+//                     contiguous write.  Grids of <= 1024 tiles: one pass straight to tiles.  Larger grids: pass 1 by
+//                     the high digit, k_log_count2 (tile histogram of pass 1's output), pass 2 by the low digit
+//   k_log_reduce      one workgroup per tile slice: LDS adds of all its records, then one read-add-write per touched
+//                     voxel (a tile with a single slice has exactly one owner: no global atomics at all)
+// Tile = 32 x 32 x 16 voxels = one LDS-sized block of the grid.  Integer (u64 fixed-point) tallies stay bit-identical
+// to the atomic path; float tallies differ by summation order only, as they already do between two atomic runs.
+//
+// Memory access shape: every streaming load is 16 bytes per lane (a lane owns 4 consecutive record indices and the
+// 4 values that go with them; the reduce reads 8 packed 2-byte positions and 8 values per lane and keeps two such
+// groups in flight), regions start at multiples of 8 records so those loads are aligned, and two partition workgroups
+// (2 x 16 waves, <= 64 VGPRs) share a CU so that one's LDS sort runs under the other's loads and stores.
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 
 #include "lt_internal.hpp"
 
@@ -29,41 +37,23 @@ template <> struct AccT<float> { typedef double type; };
 
 __device__ __forceinline__ unsigned tile_of(unsigned idx) { return idx >> kTileShift; }
 
-// records of one tile handled by one reduce workgroup; a tile with more records is split over several workgroups,
-// which bounds both the load imbalance and the same-address serialisation of the LDS adds on hot voxels
-constexpr uint32_t kReduceSlice = 131072;
+// four consecutive values: 32 bytes (two dwordx4 loads) for the 8-byte tallies, 16 bytes for f32
+template <typename TV> struct alignas(16) Quad { TV v[4]; };
 
-// Partition work item = kPartThreads lanes x kPerThread records held in registers.  16 records per lane (one log
-// chunk per item, 114 VGPRs) gives the longest per-tile runs; 8 per lane (64 VGPRs) lets a partition workgroup sit
-// beside three walk waves per SIMD when two jobs are in flight on the device (bench.py --inflight 2).
-#ifndef LT_PART_PER_THREAD
-#define LT_PART_PER_THREAD 16
-#endif
+// Partition work item = kPartThreads lanes x kPerThread records held in registers.  Half a log chunk per item:
+// 4096 records x 12 B = 48 KiB of LDS for the digit-sorted copy + 8 KiB of tables, so two workgroups fit a CU.
 constexpr int kPartThreads = 512;
-constexpr int kPerThread = LT_PART_PER_THREAD;
+constexpr int kPerThread = 8;
 constexpr uint32_t kPartItem = kPartThreads * kPerThread;       // records per work item
 constexpr uint32_t kItemsPerChunk = kLogChunk / kPartItem;
 static_assert(kLogChunk % kPartItem == 0, "a log chunk must be a whole number of partition items");
+static_assert(kPerThread % 4 == 0, "a lane loads its records four at a time");
+constexpr int kMaxBins = 1024;          // digits per pass
+constexpr uint32_t kMaxBits2 = 7;       // two-pass form: tiles per level-1 bin <= 128 (k_log_count2's LDS histogram)
+constexpr uint32_t kCountGroup = 32;    // pass-2 items whose tiles one k_log_count2 workgroup counts before it flushes
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_log_hist(const uint32_t* __restrict__ log_idx, const uint32_t* __restrict__ fill,
-                                                  uint32_t n_chunks, uint32_t* __restrict__ hist, uint32_t n_tiles)
-{
-    extern __shared__ uint32_t s_h[];
-    for (uint32_t t = threadIdx.x; t < n_tiles; t += blockDim.x) s_h[t] = 0;
-    __syncthreads();
-    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const uint32_t n = fill[c];
-        const uint32_t* src = log_idx + (size_t)c * kLogChunk;
-        for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) atomicAdd(&s_h[tile_of(src[k])], 1u);
-    }
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < n_tiles; t += blockDim.x)
-        if (s_h[t]) atomicAdd(&hist[t], s_h[t]);
-}
-
-// One workgroup of 1024 lanes; each lane owns a contiguous run of tiles (n_tiles <= 16384 -> <= 16 per lane), a
-// two-level shuffle/LDS scan gives the exclusive prefixes of the record counts and of the reduce work items.
+// scans: one workgroup of 1024 lanes, shuffle + LDS block scan
 constexpr int kScanThreads = 1024;
 
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave, uint32_t* total)
@@ -87,155 +77,357 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     return r;
 }
 
-__global__ void __launch_bounds__(kScanThreads) k_log_scan(const uint32_t* hist, uint32_t* tile_base, uint32_t* cursor1,
-                                                          uint32_t* cursor2, uint32_t* items2, uint32_t* items_r,
-                                                          uint32_t* totals, uint32_t n_tiles, uint32_t bits2)
+__device__ __forceinline__ uint32_t round_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
+
+// Per tile: where its records will live (starts padded to kTileAlign), the cursors of the final partition pass
+// (one per group; G = 1 when the histogram comes from k_log_count2), and the prefix of reduce work items (a tile
+// with more than `slice` records is split over several workgroups, which bounds both the load imbalance and the
+// same-address serialisation of the LDS adds on hot voxels).
+__global__ void __launch_bounds__(kScanThreads) k_log_scan_tiles(const uint32_t* hist, uint32_t G, uint32_t* tile_base,
+                                                                uint32_t* tile_cnt, uint32_t* cursor, uint32_t* items_r,
+                                                                uint32_t* meta, unsigned long long* job, uint32_t n_tiles)
 {
     __shared__ uint32_t s_wave[kScanThreads / 64];
-    __shared__ uint32_t s_tot[2];
+    __shared__ uint32_t s_tot[3];
     const uint32_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
-    const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
-    uint32_t cnt = 0, rit = 0;
-    for (uint32_t t = t0; t < t1; t++) { const uint32_t h = hist[t]; cnt += h; rit += (h + kReduceSlice - 1) / kReduceSlice; }
-    uint32_t base = block_exclusive_scan(cnt, s_wave, &s_tot[0]);
-    uint32_t rbase = block_exclusive_scan(rit, s_wave, &s_tot[1]);
+    const uint32_t t0 = threadIdx.x * per < n_tiles ? threadIdx.x * per : n_tiles, t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+    uint32_t cnt = 0, pad = 0;
     for (uint32_t t = t0; t < t1; t++) {
-        const uint32_t h = hist[t];
-        tile_base[t] = base; cursor2[t] = base; items_r[t] = rbase;
-        base += h; rbase += (h + kReduceSlice - 1) / kReduceSlice;   // hot tiles get several reduce workgroups
+        uint32_t h = 0;
+        for (uint32_t g = 0; g < G; g++) h += hist[t * G + g];
+        tile_cnt[t] = h; cnt += h; pad += round_up(h, kTileAlign);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) { tile_base[n_tiles] = s_tot[0]; items_r[n_tiles] = s_tot[1]; totals[0] = s_tot[0]; totals[2] = s_tot[1]; }
-    __threadfence();
-    __syncthreads();
-    // level-1 bins: few (<= 128 for 16384 tiles); tile_base of this block's own writes is visible after the fence
-    const uint32_t nb1 = (n_tiles + (1u << bits2) - 1) >> bits2;
-    uint32_t it = 0;
-    for (uint32_t b = threadIdx.x; b < nb1; b += kScanThreads) {
-        const uint32_t a0 = b << bits2, a1 = ((b + 1) << bits2) < n_tiles ? ((b + 1) << bits2) : n_tiles;
-        const uint32_t lo = tile_base[a0], hi = a1 < n_tiles ? tile_base[a1] : s_tot[0];
-        cursor1[b] = lo;
-        it = (hi - lo + kPartItem - 1) / kPartItem;
-        items2[b] = it;   // counts for now; prefixed below
+    uint32_t base = block_exclusive_scan(pad, s_wave, &s_tot[0]);
+    (void)block_exclusive_scan(cnt, s_wave, &s_tot[1]);
+    const uint32_t total = s_tot[1];
+    // records per reduce work item: ~4096 items per launch keep 256 CUs level to a few per cent while the per-item
+    // costs (zeroing and flushing a 128 KiB LDS tile) stay small against the slice's own traffic
+    uint32_t slice = round_up(total / 4096u + 1u, 8192u);
+    slice = slice < 65536u ? 65536u : (slice > (1u << 20) ? (1u << 20) : slice);
+    uint32_t rit = 0;
+    for (uint32_t t = t0; t < t1; t++) rit += (tile_cnt[t] + slice - 1) / slice;
+    uint32_t rbase = block_exclusive_scan(rit, s_wave, &s_tot[2]);
+    for (uint32_t t = t0; t < t1; t++) {
+        const uint32_t h = tile_cnt[t];
+        tile_base[t] = base; items_r[t] = rbase;
+        uint32_t run = base;
+        for (uint32_t g = 0; g < G; g++) { cursor[t * G + g] = run; run += hist[t * G + g]; }
+        base += round_up(h, kTileAlign); rbase += (h + slice - 1) / slice;
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {   // nb1 <= 1024 when bits2 = 0 (single pass: pass-2 items unused), else <= 128: serial is fine
-        uint32_t run = 0;
-        for (uint32_t b = 0; b < nb1; b++) { const uint32_t c = items2[b]; items2[b] = run; run += c; }
-        items2[nb1] = run; totals[1] = run;
+    if (threadIdx.x == 0) {
+        tile_base[n_tiles] = s_tot[0]; items_r[n_tiles] = s_tot[2];
+        meta[LM_RECORDS] = total; meta[LM_ITEMS_R] = s_tot[2]; meta[LM_SLICE] = slice;
+        if (job) { atomicAdd(&job[0], (unsigned long long)total); atomicAdd(&job[1], (unsigned long long)meta[LM_OVERFLOW]); }
+    }
+}
+
+// Two-pass form, per level-1 bin: where pass 1 puts it (starts padded to kBinAlign), one cursor per group, the prefix
+// of pass-2 work items and of k_log_count2 work items.
+__global__ void __launch_bounds__(kScanThreads) k_log_scan_bins(const uint32_t* hist1, uint32_t* bin_base, uint32_t* bin_cnt,
+                                                               uint32_t* cursor1, uint32_t* items2, uint32_t* items_c,
+                                                               uint32_t* meta, uint32_t nb1)
+{
+    __shared__ uint32_t s_wave[kScanThreads / 64];
+    __shared__ uint32_t s_tot[3];
+    const uint32_t b = threadIdx.x;
+    uint32_t h = 0;
+    if (b < nb1) for (uint32_t g = 0; g < kLogGroups; g++) h += hist1[b * kLogGroups + g];
+    const uint32_t it = (h + kPartItem - 1) / kPartItem, ic = (it + kCountGroup - 1) / kCountGroup;
+    const uint32_t base = block_exclusive_scan(round_up(h, kBinAlign), s_wave, &s_tot[0]);
+    const uint32_t ibase = block_exclusive_scan(it, s_wave, &s_tot[1]);
+    const uint32_t cbase = block_exclusive_scan(ic, s_wave, &s_tot[2]);
+    if (b < nb1) {
+        bin_base[b] = base; bin_cnt[b] = h; items2[b] = ibase; items_c[b] = cbase;
+        uint32_t run = base;
+        for (uint32_t g = 0; g < kLogGroups; g++) { cursor1[b * kLogGroups + g] = run; run += hist1[b * kLogGroups + g]; }
+    }
+    if (b == 0) {
+        bin_base[nb1] = s_tot[0]; items2[nb1] = s_tot[1]; items_c[nb1] = s_tot[2];
+        meta[LM_ITEMS2] = s_tot[1]; meta[LM_ITEMS_C] = s_tot[2];
+    }
+}
+
+// largest a in [0, n) with prefix[a] <= x (prefix ascending, prefix[0] = 0)
+__device__ __forceinline__ uint32_t upper_slot(const uint32_t* prefix, uint32_t n, uint32_t x)
+{
+    uint32_t a = 0, b = n;
+    while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (prefix[m] <= x) a = m; else b = m; }
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Rank of a record inside its digit, for one record slot of every lane of a wave.  A plain returning LDS atomic per
+// lane serialises on the hot digits (the records of a chunk cluster in the few tiles around the source: most lanes of
+// a wave-instruction hit the same counter).  Here the lanes that share the digit of the first active lane, and those
+// that share the digit of the first lane left after that, are counted with a ballot and added by ONE lane each; only
+// the rest add for themselves.  Issue and use are split so that the atomics of all record slots are in flight at once.
+struct RankMasks { unsigned long long m0, m1; int l0, l1; };
+
+__device__ __forceinline__ RankMasks rank_masks(uint32_t d, bool valid)
+{
+    RankMasks r; r.m0 = r.m1 = 0ull; r.l0 = r.l1 = 0;
+    const unsigned long long act = __ballot(valid);
+    if (act != 0ull) {
+        r.l0 = __ffsll((long long)act) - 1;
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, r.l0);
+        r.m0 = __ballot(valid && d == d0);
+        const unsigned long long rest = act & ~r.m0;
+        if (rest != 0ull) {
+            r.l1 = __ffsll((long long)rest) - 1;
+            const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)d, r.l1);
+            r.m1 = __ballot(valid && d == d1);
+        }
+    }
+    return r;
+}
+
+__device__ __forceinline__ uint32_t rank_issue(uint32_t* s_cnt, uint32_t d, bool valid, int lane)
+{
+    const RankMasks r = rank_masks(d, valid);
+    const bool in0 = (r.m0 >> lane) & 1ull, in1 = (r.m1 >> lane) & 1ull;
+    const bool lead0 = in0 && lane == r.l0, lead1 = in1 && lane == r.l1;
+    const uint32_t amount = lead0 ? (uint32_t)__popcll(r.m0) : (lead1 ? (uint32_t)__popcll(r.m1) : 1u);
+    uint32_t ret = 0;
+    if (lead0 || lead1 || (valid && !in0 && !in1)) ret = atomicAdd(&s_cnt[d], amount);   // one ds_add_rtn_u32
+    return ret;
+}
+
+__device__ __forceinline__ uint32_t rank_finish(uint32_t ret, uint32_t d, bool valid, int lane)
+{
+    const RankMasks r = rank_masks(d, valid);
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)ret, r.l0), b1 = (uint32_t)__builtin_amdgcn_readlane((int)ret, r.l1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if ((r.m0 >> lane) & 1ull) return b0 + (uint32_t)__popcll(r.m0 & below);
+    if ((r.m1 >> lane) & 1ull) return b1 + (uint32_t)__popcll(r.m1 & below);
+    return ret;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Two-pass form: descriptor of every pass-2 work item (where its records start in pass 1's output, how many, which
+// level-1 bin), so that the partition reads ONE record per item -- an iteration ahead -- instead of searching the
+// bin prefix with dependent loads while 511 lanes wait.
+__global__ void __launch_bounds__(256) k_log_items2(LogReduceParams L)
+{
+    const uint32_t nb1 = (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2;
+    const uint32_t n_items = L.meta[LM_ITEMS2];
+    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < n_items; item += gridDim.x * blockDim.x) {
+        const uint32_t a = upper_slot(L.items2, nb1, item);
+        const uint32_t done = (item - L.items2[a]) * kPartItem, left = L.bin_cnt[a] - done;
+        reinterpret_cast<uint4*>(L.itab)[item] = make_uint4(L.bin_base[a] + done, left < kPartItem ? left : kPartItem, a, 0u);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Partition work item: <= 4096 records.  Registers hold the item (16 records per lane), LDS holds the histogram
-// and the digit-sorted copy; each digit's run leaves as one contiguous, coalesced write.
-constexpr int kMaxBins = 1024;
-
+// Partition work item: <= 4096 records.  Registers hold the item (8 records per lane, loaded 16 bytes at a time), LDS
+// holds the digit histogram / offsets and the digit-sorted copy; each digit's run leaves as one contiguous write.
+// Software pipeline: the next item's loads are issued as soon as this item's records sit in LDS (their registers are
+// free then), so they fly during the write-out; the cursor atomics are issued before the digit scan and collected
+// after the LDS scatter.
+#ifndef LT_PART_WAVES
+#define LT_PART_WAVES 4
+#endif
 template <typename TV, int PASS>
-__global__ void __launch_bounds__(kPartThreads) k_log_part(LogReduceParams L)
+__global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogReduceParams L)
 {
-    __shared__ uint32_t s_hist[kMaxBins], s_off[kMaxBins + 1], s_gbase[kMaxBins];
-    __shared__ uint32_t s_range[3], s_next;
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // digit-sorted copy of the item (96 KiB at 12 B)
-    TV* s_val = reinterpret_cast<TV*>(s_dyn);
-    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_dyn + (size_t)kPartItem * sizeof(TV));
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    TV* s_val = reinterpret_cast<TV*>(s_dyn);                                                   // [kPartItem]
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_dyn + (size_t)kPartItem * sizeof(TV));      // [kPartItem]
+    uint32_t* s_a = s_key + kPartItem;        // [kMaxBins + 2] digit counts, then exclusive offsets
+    uint32_t* s_b = s_a + kMaxBins + 2;       // [kMaxBins]     global base of the digit's run minus its offset
+    __shared__ uint32_t s_wsum[kPartThreads / 64];
 
-    // Persistent workgroups pull work items from a device counter; the item count lives in device memory too
-    // (chunks the walk claimed / items the scan derived), so the host never has to read anything back.
-    uint32_t n_items = PASS == 1 ? L.chunks_used[0] : L.totals[1];
-    if (PASS == 1) n_items = (n_items > L.cap_chunks ? L.cap_chunks : n_items) * kItemsPerChunk;
-  for (;;) {
-    if (threadIdx.x == 0) s_next = atomicAdd(&L.work[PASS - 1], 1u);
-    __syncthreads();
-    const uint32_t item = s_next;
-    if (item >= n_items) break;
-    const uint32_t nb1 = (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nb1 = L.bits2 ? (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2 : L.n_tiles;
     const uint32_t mask2 = (1u << L.bits2) - 1;
+    const uint32_t nb = PASS == 1 ? nb1 : (1u << L.bits2);
     const bool final_pass = PASS == 2 || L.bits2 == 0;
-    const uint32_t* in_idx; const TV* in_val; uint32_t* out_idx; TV* out_val; uint32_t* cursor; uint32_t nb;
-    uint32_t lo, n;
-    if (PASS == 1) {
-        in_idx = L.log_idx; in_val = reinterpret_cast<const TV*>(L.log_val);
-        out_idx = L.tmp_idx; out_val = reinterpret_cast<TV*>(L.tmp_val);
-        const uint32_t fill = L.log_fill[item / kItemsPerChunk], part = (item % kItemsPerChunk) * kPartItem;
-        lo = item * kPartItem; n = fill > part ? (fill - part < kPartItem ? fill - part : kPartItem) : 0;
-        cursor = L.cursor1; nb = nb1;
-    } else {
-        in_idx = L.tmp_idx; in_val = reinterpret_cast<const TV*>(L.tmp_val);
-        out_idx = const_cast<uint32_t*>(L.log_idx); out_val = reinterpret_cast<TV*>(const_cast<void*>(L.log_val));
-        if (threadIdx.x == 0) {  // which level-1 bin does this item belong to? (items2 is a prefix over bins)
-            uint32_t a = 0, b = nb1;
-            while (b - a > 1) { uint32_t m = (a + b) >> 1; if (L.items2[m] <= item) a = m; else b = m; }
-            const uint32_t t0 = a << L.bits2, t1 = ((a + 1) << L.bits2) < L.n_tiles ? ((a + 1) << L.bits2) : L.n_tiles;
-            const uint32_t rlo = L.tile_base[t0] + (item - L.items2[a]) * kPartItem, rhi = L.tile_base[t1];
-            s_range[0] = rlo; s_range[1] = rhi - rlo < kPartItem ? rhi - rlo : kPartItem; s_range[2] = a;
-        }
-        __syncthreads();
-        lo = s_range[0]; n = s_range[1];
-        cursor = L.cursor2 + (s_range[2] << L.bits2); nb = 1u << L.bits2;
-    }
-    for (uint32_t d = threadIdx.x; d < nb; d += kPartThreads) s_hist[d] = 0;
-    __syncthreads();
+    // the item count lives in device memory (chunks the walk claimed / items the scan derived), so the host never has
+    // to read anything back between the kernels of a batch
+    uint32_t n_items = PASS == 1 ? L.meta[LM_NEXT] : L.meta[LM_ITEMS2];
+    if (PASS == 1) n_items = (n_items > L.cap_chunks ? L.cap_chunks : n_items) * kItemsPerChunk;
+    const uint32_t* in_idx = PASS == 1 ? L.log_idx : L.tmp_idx;
+    const TV* in_val = reinterpret_cast<const TV*>(PASS == 1 ? L.log_val : L.tmp_val);
+    uint32_t* out_idx = PASS == 1 ? L.tmp_idx : const_cast<uint32_t*>(L.log_idx);
+    TV* out_val = reinterpret_cast<TV*>(PASS == 1 ? L.tmp_val : const_cast<void*>(L.log_val));
+    auto digit = [&](uint32_t k_) { const uint32_t t_ = tile_of(k_); return PASS == 1 ? (t_ >> L.bits2) : (t_ & mask2); };
 
-    uint32_t key[kPerThread], rank[kPerThread];
+    // item descriptor: PASS 1: x = the chunk's fill word (records | group << 24); PASS 2: (start, records, bin, -)
+    auto describe = [&](uint32_t it) -> uint4 {
+        if (PASS == 1) return make_uint4(L.log_fill[it / kItemsPerChunk], 0u, 0u, 0u);
+        return reinterpret_cast<const uint4*>(L.itab)[it];
+    };
+    uint32_t key[kPerThread], ret[kPerThread];
     TV val[kPerThread];
+    // lane owns records k = g * 2048 + tid * 4 + j: 16 B of indices and 16 / 32 B of values per load group.  Groups are
+    // read whole and unconditionally: the bytes behind an item's end are mapped (slack behind every buffer), and
+    // records at k >= n are masked out below.
+    auto load_item = [&](uint32_t lo_) {
 #pragma unroll
-    for (int r = 0; r < kPerThread; r++) {
-        const uint32_t k = threadIdx.x + r * kPartThreads;
-        if (k < n) { key[r] = in_idx[lo + k]; val[r] = in_val[lo + k]; }
-    }
+        for (int g = 0; g < kPerThread / 4; g++) {
+            const uint32_t k = (uint32_t)g * (kPartThreads * 4) + threadIdx.x * 4;
+            const uint4 q = *reinterpret_cast<const uint4*>(in_idx + lo_ + k);
+            const Quad<TV> v = *reinterpret_cast<const Quad<TV>*>(in_val + lo_ + k);
+            key[4 * g] = q.x; key[4 * g + 1] = q.y; key[4 * g + 2] = q.z; key[4 * g + 3] = q.w;
 #pragma unroll
-    for (int r = 0; r < kPerThread; r++) {
-        const uint32_t k = threadIdx.x + r * kPartThreads;
-        if (k < n) {
-            const uint32_t t = tile_of(key[r]);
-            const uint32_t d = PASS == 1 ? (t >> L.bits2) : (t & mask2);
-            rank[r] = atomicAdd(&s_hist[d], 1u);
+            for (int j = 0; j < 4; j++) val[4 * g + j] = v.v[j];
         }
+    };
+
+    // equal-sized work items, strided over the grid: no shared work counter -- one word sustains only ~90 returning
+    // atomics per microsecond, less than the item rate of this kernel
+    uint32_t item = blockIdx.x;
+    if (item >= n_items) return;
+    uint4 ds = describe(item);
+    load_item(PASS == 1 ? item * kPartItem : ds.x);
+  for (; item < n_items; item += gridDim.x) {
+    const uint32_t next = item + gridDim.x;
+    for (uint32_t d = threadIdx.x; d < nb + 2; d += kPartThreads) s_a[d] = 0;
+    uint32_t n, cstride;
+    uint32_t* cursor;
+    if (PASS == 1) {
+        const uint32_t fill = ds.x & kFillMask, part = (item % kItemsPerChunk) * kPartItem;
+        n = fill > part ? (fill - part < kPartItem ? fill - part : kPartItem) : 0;
+        cursor = L.cursor1 + (ds.x >> 24); cstride = kLogGroups;       // the cursors of the chunk's group
+    } else {
+        n = ds.y;
+        cursor = L.cursor2 + (ds.z << L.bits2); cstride = 1;
     }
     __syncthreads();
-    if (threadIdx.x < 64) {  // exclusive prefix over <= 512 bins by one wave: 8 bins per lane + wave scan
-        const uint32_t per = (nb + 63) / 64;
-        uint32_t sum = 0;
-        for (uint32_t q = 0; q < per; q++) { const uint32_t d = threadIdx.x * per + q; if (d < nb) sum += s_hist[d]; }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { uint32_t o = __shfl_up(incl, off, 64); if ((int)threadIdx.x >= off) incl += o; }
-        uint32_t run = incl - sum;
-        for (uint32_t q = 0; q < per; q++) { const uint32_t d = threadIdx.x * per + q; if (d < nb) { s_off[d] = run; run += s_hist[d]; } }
-    }
-    for (uint32_t d = threadIdx.x; d < nb; d += kPartThreads)
-        if (s_hist[d]) s_gbase[d] = atomicAdd(&cursor[d], s_hist[d]);   // one returning atomic per non-empty digit
-    __syncthreads();
+    // ---- rank inside the digit
 #pragma unroll
     for (int r = 0; r < kPerThread; r++) {
-        const uint32_t k = threadIdx.x + r * kPartThreads;
+        const uint32_t k = (uint32_t)(r >> 2) * (kPartThreads * 4) + threadIdx.x * 4 + (r & 3);
+        ret[r] = rank_issue(s_a, digit(key[r]), k < n, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < kPerThread; r++) {
+        const uint32_t k = (uint32_t)(r >> 2) * (kPartThreads * 4) + threadIdx.x * 4 + (r & 3);
+        ret[r] = rank_finish(ret[r], digit(key[r]), k < n, lane);
+    }
+    __syncthreads();
+    // ---- space for every non-empty digit: one returning global atomic each, issued before the scan so that its
+    //      latency runs under the scan and the LDS scatter
+    uint32_t c0 = 0, c1 = 0, g0 = 0, g1 = 0, incl;
+    {
+        const uint32_t d = 2 * threadIdx.x;
+        if (d < nb) { const uint2 cc = *reinterpret_cast<const uint2*>(&s_a[d]); c0 = cc.x; c1 = d + 1 < nb ? cc.y : 0; }
+        if (c0) g0 = atomicAdd(&cursor[d * cstride], c0);
+        if (c1) g1 = atomicAdd(&cursor[(d + 1) * cstride], c1);
+        // ---- exclusive prefix over the digits, in place: two digits per lane, wave scan, wave totals through LDS
+        incl = c0 + c1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        if (lane == 63) s_wsum[wave] = incl;
+    }
+    __syncthreads();
+    uint32_t ex = 0;
+    {
+        uint32_t before = 0;
+#pragma unroll
+        for (int w = 0; w < kPartThreads / 64; w++) before += w < wave ? s_wsum[w] : 0;
+        ex = before + incl - (c0 + c1);
+        const uint32_t d = 2 * threadIdx.x;
+        if (d < nb) *reinterpret_cast<uint2*>(&s_a[d]) = make_uint2(ex, ex + c0);
+    }
+    __syncthreads();
+    // ---- digit-sorted copy in LDS
+#pragma unroll
+    for (int r = 0; r < kPerThread; r++) {
+        const uint32_t k = (uint32_t)(r >> 2) * (kPartThreads * 4) + threadIdx.x * 4 + (r & 3);
         if (k < n) {
-            const uint32_t t = tile_of(key[r]);
-            const uint32_t d = PASS == 1 ? (t >> L.bits2) : (t & mask2);
-            const uint32_t p = s_off[d] + rank[r];
+            const uint32_t p = s_a[digit(key[r])] + ret[r];
             s_key[p] = key[r]; s_val[p] = val[r];
         }
     }
+    // ---- the registers are free: request the next item now, it arrives during the write-out
+    if (next < n_items) {
+        ds = describe(next);
+        load_item(PASS == 1 ? next * kPartItem : ds.x);
+    }
+    {
+        const uint32_t d = 2 * threadIdx.x;
+        if (c0) s_b[d] = g0 - ex;
+        if (c1) s_b[d + 1] = g1 - (ex + c0);
+    }
     __syncthreads();
-    for (uint32_t p = threadIdx.x; p < n; p += kPartThreads) {
-        const uint32_t kk = s_key[p];
-        const uint32_t t = tile_of(kk);
-        const uint32_t d = PASS == 1 ? (t >> L.bits2) : (t & mask2);
-        const uint32_t dst = s_gbase[d] + (p - s_off[d]);
-        // the last pass leaves a tile's records together, so only the 14-bit position inside the tile is kept: 2 bytes
-        // instead of 4 written here and read by the reduce
-        if (final_pass) reinterpret_cast<uint16_t*>(out_idx)[dst] = (uint16_t)(kk & (kTileSize - 1));
-        else out_idx[dst] = kk;
-        out_val[dst] = s_val[p];
+    // ---- write out: consecutive sorted positions of one digit are consecutive in memory
+#pragma unroll
+    for (int i = 0; i < kPerThread; i++) {
+        const uint32_t p = threadIdx.x + (uint32_t)i * kPartThreads;
+        if (p < n) {
+            const uint32_t kk = s_key[p];
+            const uint32_t dst = s_b[digit(kk)] + p;
+            // the last pass leaves a tile's records together, so only the 14-bit position inside the tile is kept:
+            // 2 bytes instead of 4 written here and read by the reduce
+            if (final_pass) reinterpret_cast<uint16_t*>(out_idx)[dst] = (uint16_t)(kk & (kTileSize - 1));
+            else out_idx[dst] = kk;
+            out_val[dst] = s_val[p];
+        }
     }
     __syncthreads();   // LDS is reused by the next item
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Two-pass form: records per tile, counted from pass 1's output (indices only).  A workgroup takes up to kCountGroup
+// consecutive pass-2 items of ONE level-1 bin, counts their tiles in an LDS histogram of <= 128 entries and flushes it
+// with one global atomic per non-empty tile.
+__global__ void __launch_bounds__(kPartThreads) k_log_count2(LogReduceParams L)
+{
+    __shared__ uint32_t s_cnt[1u << kMaxBits2];
+    __shared__ uint32_t s_range[3];
+    const uint32_t nb1 = (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2, mask2 = (1u << L.bits2) - 1;
+    const uint32_t n_items = L.meta[LM_ITEMS_C];
+    const int lane = threadIdx.x & 63;
+  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    if (threadIdx.x == 0) {
+        const uint32_t a = upper_slot(L.items_c, nb1, item);
+        const uint32_t done = (item - L.items_c[a]) * (kCountGroup * kPartItem), left = L.bin_cnt[a] - done;
+        s_range[0] = L.bin_base[a] + done; s_range[1] = left < kCountGroup * kPartItem ? left : kCountGroup * kPartItem;
+        s_range[2] = a;
+    }
+    if (threadIdx.x < (1u << kMaxBits2)) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lo = s_range[0], n = s_range[1], bin = s_range[2];
+    for (uint32_t k = threadIdx.x * 4; k < n; k += kPartThreads * 4) {    // lo is a multiple of 4: aligned 16-byte loads
+        const uint4 q = *reinterpret_cast<const uint4*>(L.tmp_idx + lo + k);
+        const uint32_t kk[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t d = tile_of(kk[j]) & mask2;
+            const bool valid = k + j < n;
+            // same aggregation as the partition's ranking: the first lane's tile is added once for all its lanes
+            const unsigned long long act = __ballot(valid);
+            if (act != 0ull) {
+                const int l0 = __ffsll((long long)act) - 1;
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, l0);
+                const unsigned long long m0 = __ballot(valid && d == d0);
+                if (lane == l0) atomicAdd(&s_cnt[d0], (uint32_t)__popcll(m0));
+                else if (valid && d != d0) atomicAdd(&s_cnt[d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < (1u << L.bits2)) {
+        const uint32_t t = (bin << L.bits2) + threadIdx.x, v = s_cnt[threadIdx.x];
+        if (v && t < L.n_tiles) __hip_atomic_fetch_add(&L.hist[t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 constexpr int kReduceThreads = 512;
+
+template <typename TV, typename AT>
+__device__ __forceinline__ void add8(AT* s_tile, const uint4 q, const Quad<TV>& a, const Quad<TV>& b)
+{
+    const uint32_t m = kTileSize - 1;
+    lds_add(&s_tile[q.x & m], (AT)a.v[0]); lds_add(&s_tile[(q.x >> 16) & m], (AT)a.v[1]);
+    lds_add(&s_tile[q.y & m], (AT)a.v[2]); lds_add(&s_tile[(q.y >> 16) & m], (AT)a.v[3]);
+    lds_add(&s_tile[q.z & m], (AT)b.v[0]); lds_add(&s_tile[(q.z >> 16) & m], (AT)b.v[1]);
+    lds_add(&s_tile[q.w & m], (AT)b.v[2]); lds_add(&s_tile[(q.w >> 16) & m], (AT)b.v[3]);
+}
 
 template <typename TV>
 __global__ void __launch_bounds__(kReduceThreads) k_log_reduce(LogReduceParams L)
@@ -243,40 +435,57 @@ __global__ void __launch_bounds__(kReduceThreads) k_log_reduce(LogReduceParams L
     typedef typename AccT<TV>::type AT;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     AT* s_tile = reinterpret_cast<AT*>(s_raw);
-    __shared__ uint32_t s_item[3], s_next;
-    const uint32_t n_items = L.totals[2];
-  for (;;) {
-    if (threadIdx.x == 0) s_next = atomicAdd(&L.work[2], 1u);
-    __syncthreads();
-    const uint32_t item = s_next;
-    if (item >= n_items) break;
-    if (threadIdx.x == 0) {   // tile of this work item: items_r is a prefix over tiles
-        uint32_t a = 0, b = L.n_tiles;
-        while (b - a > 1) { uint32_t m = (a + b) >> 1; if (L.items_r[m] <= item) a = m; else b = m; }
-        const uint32_t lo = L.tile_base[a] + (item - L.items_r[a]) * kReduceSlice, end = L.tile_base[a + 1];
-        s_item[0] = a; s_item[1] = lo; s_item[2] = end - lo < kReduceSlice ? end : lo + kReduceSlice;
-    }
+    __shared__ uint32_t s_item[2][5];     // [tile, lo, hi, slices of the tile, item] of the current and the next work item
+    const uint32_t n_items = L.meta[LM_ITEMS_R], slice = L.meta[LM_SLICE];
+    // work items differ in size (a slice holds up to `slice` records, most tiles far fewer): they are pulled from a
+    // device counter (a few thousand per launch).  Lane 0 claims and describes the NEXT item while the workgroup adds
+    // the current one: the tile search (dependent loads) is off the critical path.
+    auto claim = [&](uint32_t* out) {
+        const uint32_t item = atomicAdd(&L.meta[LM_WORK], 1u);
+        out[4] = item;
+        if (item < n_items) {
+            const uint32_t a = upper_slot(L.items_r, L.n_tiles, item);
+            const uint32_t lo = L.tile_base[a] + (item - L.items_r[a]) * slice, end = L.tile_base[a] + L.tile_cnt[a];
+            out[0] = a; out[1] = lo; out[2] = end - lo < slice ? end : lo + slice;
+            out[3] = L.items_r[a + 1] - L.items_r[a];
+        }
+    };
+    if (threadIdx.x == 0) claim(s_item[0]);
     for (uint32_t v = threadIdx.x; v < kTileSize; v += kReduceThreads) s_tile[v] = 0;
     __syncthreads();
-    const uint32_t t = s_item[0], lo = s_item[1], hi = s_item[2];
-    const bool shared_tile = L.items_r[t + 1] - L.items_r[t] > 1;
+  for (int cur = 0;; cur ^= 1) {
+    if (s_item[cur][4] >= n_items) break;
+    if (threadIdx.x == 0) claim(s_item[cur ^ 1]);
+    const uint32_t t = s_item[cur][0], lo = s_item[cur][1], hi = s_item[cur][2];
+    const bool shared_tile = L.flush_atomic || s_item[cur][3] > 1;
     const uint16_t* idx = reinterpret_cast<const uint16_t*>(L.log_idx);   // in-tile positions, see k_log_part's last pass
     const TV* val = reinterpret_cast<const TV*>(L.log_val);
-    // four independent records in flight per lane (the tile pins the workgroup at 8 waves per CU, so memory-level
-    // parallelism has to come from the instruction stream)
-    uint32_t k = lo + threadIdx.x;
-    for (; k + 3 * kReduceThreads < hi; k += 4 * kReduceThreads) {
-        const uint32_t i0 = idx[k], i1 = idx[k + kReduceThreads], i2 = idx[k + 2 * kReduceThreads], i3 = idx[k + 3 * kReduceThreads];
-        const TV v0 = val[k], v1 = val[k + kReduceThreads], v2 = val[k + 2 * kReduceThreads], v3 = val[k + 3 * kReduceThreads];
-        lds_add(&s_tile[i0 & (kTileSize - 1)], (AT)v0); lds_add(&s_tile[i1 & (kTileSize - 1)], (AT)v1);
-        lds_add(&s_tile[i2 & (kTileSize - 1)], (AT)v2); lds_add(&s_tile[i3 & (kTileSize - 1)], (AT)v3);
+    // `lo` is a multiple of 8 records (tile starts are padded, slices are multiples of 8192): a lane takes 8
+    // consecutive records with one 16-byte load of positions and 2 (f32) / 4 (f64, u64) 16-byte loads of values, and
+    // keeps two such groups in flight -- the tile pins the workgroup at 8 waves per CU, so the memory-level
+    // parallelism (~80 KB per CU) has to come from the instruction stream.
+    const uint32_t n8 = (hi - lo) >> 3;
+    const uint4* idx8 = reinterpret_cast<const uint4*>(idx + lo);
+    const Quad<TV>* val4 = reinterpret_cast<const Quad<TV>*>(val + lo);
+    uint32_t g = threadIdx.x;
+    for (; g + kReduceThreads < n8; g += 2 * kReduceThreads) {
+        const uint4 q0 = idx8[g], q1 = idx8[g + kReduceThreads];
+        const Quad<TV> a0 = val4[2 * g], b0 = val4[2 * g + 1];
+        const Quad<TV> a1 = val4[2 * (g + kReduceThreads)], b1 = val4[2 * (g + kReduceThreads) + 1];
+        add8<TV, AT>(s_tile, q0, a0, b0);
+        add8<TV, AT>(s_tile, q1, a1, b1);
     }
-    for (; k < hi; k += kReduceThreads) lds_add(&s_tile[idx[k] & (kTileSize - 1)], (AT)val[k]);
+    if (g < n8) { const uint4 q0 = idx8[g]; const Quad<TV> a0 = val4[2 * g], b0 = val4[2 * g + 1]; add8<TV, AT>(s_tile, q0, a0, b0); }
+    {
+        const uint32_t k = lo + (n8 << 3) + threadIdx.x;
+        if (k < hi) lds_add(&s_tile[idx[k] & (kTileSize - 1)], (AT)val[k]);
+    }
     __syncthreads();
     TV* grid = reinterpret_cast<TV*>(L.grid);
     const uint32_t tx = t % L.ntx, ty = (t / L.ntx) % L.nty, tz = t / (L.ntx * L.nty);
     for (uint32_t v = threadIdx.x; v < kTileSize; v += kReduceThreads) {
         const TV a = (TV)s_tile[v];
+        s_tile[v] = 0;                                   // ready for the next item
         const uint32_t vx = (tx << kTileBX) | (v & 31u), vy = (ty << kTileBY) | ((v >> 5) & 31u), vz = (tz << kTileBZ) | (v >> 10);
         if (a != 0 && vx < L.nx && vy < L.ny && vz < L.nz) {
             TV* dst = &grid[((size_t)vz * L.ny + vy) * L.nx + vx];
@@ -284,49 +493,56 @@ __global__ void __launch_bounds__(kReduceThreads) k_log_reduce(LogReduceParams L
             else *dst += a;   // exclusive owner of this tile: plain read-add-write
         }
     }
-    __syncthreads();   // the LDS tile is re-zeroed for the next item
+    __syncthreads();   // the LDS tile is clean again, s_item[cur ^ 1] is complete
   }
 }
 
 }  // namespace
 
-hipError_t launch_log_hist(const LogReduceParams& L, hipStream_t s)
+uint32_t log_part_item() { return kPartItem; }
+
+hipError_t launch_log_scan_tiles(const LogReduceParams& L, hipStream_t s)
 {
-    if (L.n_chunks == 0) return hipSuccess;
-    const unsigned blocks = L.n_chunks < 2048 ? L.n_chunks : 2048;
-    hipLaunchKernelGGL(k_log_hist, dim3(blocks), dim3(256), L.n_tiles * sizeof(uint32_t), s, L.log_idx, L.log_fill,
-                       L.n_chunks, L.hist, L.n_tiles);
+    // one-pass form: the only partition pass is the final one and runs on cursor1
+    hipLaunchKernelGGL(k_log_scan_tiles, dim3(1), dim3(kScanThreads), 0, s, L.hist, L.bits2 ? 1u : kLogGroups, L.tile_base, L.tile_cnt,
+                       L.bits2 ? L.cursor2 : L.cursor1, L.items_r, L.meta, L.job, L.n_tiles);
     return hipGetLastError();
 }
 
-hipError_t launch_log_scan(const LogReduceParams& L, hipStream_t s)
+hipError_t launch_log_scan_bins(const LogReduceParams& L, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_log_scan, dim3(1), dim3(kScanThreads), 0, s, L.hist, L.tile_base, L.cursor1, L.cursor2, L.items2, L.items_r, L.totals,
-                       L.n_tiles, L.bits2);
+    const uint32_t nb1 = (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2;
+    if (L.bits2 == 0 || L.bits2 > kMaxBits2 || nb1 > (uint32_t)kMaxBins) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_log_scan_bins, dim3(1), dim3(kScanThreads), 0, s, L.hist1, L.bin_base, L.bin_cnt, L.cursor1, L.items2,
+                       L.items_c, L.meta, nb1);
     return hipGetLastError();
 }
 
-// persistent grids: as many workgroups as are resident at once (occupancy query x CUs)
-static unsigned persistent_blocks(const void* fn, int threads, size_t lds)
+// persistent grids: as many workgroups as are resident at once (occupancy query x CUs); the result is cached per
+// kernel (a benign race: every thread computes the same number)
+static unsigned persistent_blocks(std::atomic<unsigned>& cache, const void* fn, int threads, size_t lds)
 {
+    unsigned b = cache.load(std::memory_order_relaxed);
+    if (b) return b;
     int per_cu = 0, dev = 0, cus = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    return (unsigned)(per_cu * cus);
+    b = (unsigned)(per_cu * cus);
+    cache.store(b, std::memory_order_relaxed);
+    return b;
 }
 
 template <typename TV, int PASS> static hipError_t launch_part_t(const LogReduceParams& L, hipStream_t s)
 {
-    const size_t lds = (size_t)kPartItem * (sizeof(TV) + sizeof(uint32_t));
+    const size_t lds = (size_t)kPartItem * (sizeof(TV) + sizeof(uint32_t)) + (size_t)(2 * kMaxBins + 2) * sizeof(uint32_t);
     const void* fn = reinterpret_cast<const void*>(&k_log_part<TV, PASS>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    static unsigned blocks = 0;   // per instantiation
-    if (!blocks) blocks = persistent_blocks(fn, kPartThreads, lds);
-    hipLaunchKernelGGL((k_log_part<TV, PASS>), dim3(blocks), dim3(kPartThreads), lds, s, L);
+    static std::atomic<unsigned> blocks{0};   // per instantiation
+    hipLaunchKernelGGL((k_log_part<TV, PASS>), dim3(persistent_blocks(blocks, fn, kPartThreads, lds)), dim3(kPartThreads), lds, s, L);
     return hipGetLastError();
 }
 template <int PASS> static hipError_t launch_part(const LogReduceParams& L, hipStream_t s)
@@ -336,7 +552,19 @@ template <int PASS> static hipError_t launch_part(const LogReduceParams& L, hipS
     return launch_part_t<unsigned long long, PASS>(L, s);
 }
 hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s) { return launch_part<1>(L, s); }
-hipError_t launch_log_part2(const LogReduceParams& L, hipStream_t s) { return launch_part<2>(L, s); }
+hipError_t launch_log_part2(const LogReduceParams& L, hipStream_t s)
+{
+    // tiles of pass 1's output are counted first: the scan of those counts places pass 2's output
+    static std::atomic<unsigned> blocks{0};
+    const void* fn = reinterpret_cast<const void*>(&k_log_count2);
+    hipLaunchKernelGGL(k_log_count2, dim3(persistent_blocks(blocks, fn, kPartThreads, 0)), dim3(kPartThreads), 0, s, L);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if ((e = launch_log_scan_tiles(L, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_log_items2, dim3(1024), dim3(256), 0, s, L);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return launch_part<2>(L, s);
+}
 
 template <typename TV> static hipError_t launch_reduce_t(const LogReduceParams& L, hipStream_t s)
 {
@@ -346,9 +574,8 @@ template <typename TV> static hipError_t launch_reduce_t(const LogReduceParams& 
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    static unsigned blocks = 0;
-    if (!blocks) blocks = persistent_blocks(fn, kReduceThreads, lds);
-    hipLaunchKernelGGL(k_log_reduce<TV>, dim3(blocks), dim3(kReduceThreads), lds, s, L);
+    static std::atomic<unsigned> blocks{0};
+    hipLaunchKernelGGL(k_log_reduce<TV>, dim3(persistent_blocks(blocks, fn, kReduceThreads, lds)), dim3(kReduceThreads), lds, s, L);
     return hipGetLastError();
 }
 hipError_t launch_log_reduce(const LogReduceParams& L, hipStream_t s)

@@ -557,35 +557,116 @@ def test_light_subpath_vertices(ctx, name):
     np.testing.assert_allclose(paths[7][1].point, v["point"][7, 1], atol=1e-12)
     with pytest.raises(Exception):
         ctx.read_vertices(n)       # nothing captured by the last launch
+    # a capture size changed AFTER the capturing launch must not resize the read (it would read out of bounds)
+    prob.apply(ctx, "f64"); ctx.set_vertex_capture(4); ctx.launch(100, seed=31); ctx.sync()
+    ctx.set_vertex_capture(9)
+    with pytest.raises(Exception):
+        ctx.read_vertices(100)
+    ctx.set_vertex_capture(4)
+    v4, cnt4 = ctx.read_vertices(100)
+    assert v4.shape == (100, 4) and np.array_equal(v4["point"][:, :4][cnt4[:, None] > np.arange(4)[None, :]],
+                                                    v["point"][:100, :4][cnt4[:, None] > np.arange(4)[None, :]])
+    ctx.set_vertex_capture(0)
 
 
 # ---------------------------------------------------------------- the two deposition paths
 def test_log_tally_equals_atomic_tally(ctx):
     """LT_MODE_LOG (deposit log -> tile partition -> LDS reduce) against LT_MODE_ATOMIC: bit-identical fixed-point
-    grids, also when the log is far too small (many batches, overflow diverted to atomics) and on a grid whose
-    size is not a multiple of the 16384-voxel tile; float tallies equal up to summation order."""
+    grids -- with an ample log (one batch), with a log budget that forces several batches, with one so small that
+    most records overflow to the atomic fallback, with the batches alternating between the ctx's two lanes
+    (lt_set_overlap 2), with the two-pass partition forced on a small grid, and on a grid whose size is not a
+    multiple of the 16384-voxel tile; float tallies equal up to summation order.  Every regime is checked to have
+    really been exercised (batches, overflow, lanes reported by lt_last_log_info).  Fresh contexts: a log budget
+    smaller than an earlier allocation must be honoured all the same."""
+    import light_transport_amd as lt
     odd = S.Problem([(0.1, 10.0, 0.9, 1.0)], (100, 70, 33), (-5.0, -3.5, 0.0), (0.1,) * 3,
                     layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))
     big = S.Problem([(0.1, 10.0, 0.9, 1.0)], (300, 300, 200), (-15.0, -15.0, 0.0), (0.1,) * 3,
-                    layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))   # 1099 tiles: two-level partition
+                    layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))   # 1300 tiles: two-pass partition
+    regimes = (("atomic", 0, 1, None), ("log", 8 << 30, 1, None), ("log", 48 << 20, 1, None), ("log", 4 << 20, 1, None),
+               ("log", 8 << 30, 2, None), ("log", 48 << 20, 2, None), ("log", 8 << 30, 1, "3"), ("log", 48 << 20, 2, "2"))
     for prob, n in ((S.slab(), 300000), (odd, 300000), (S.cornell(64), 100000), (big, 300000)):
         grids = {}
-        for mode, log_bytes in (("atomic", 0), ("log", 8 << 30), ("log", 48 << 20)):
-            prob.apply(ctx, "u64fx"); ctx.set_tally_mode(mode, log_bytes)
-            ctx.launch(n, seed=5); ctx.sync()
-            grids[(mode, log_bytes)] = (ctx.read_grid_raw(), ctx.read_counters())
-        ref, cref = grids[("atomic", 0)]
+        c2 = lt.Context(0)        # ample logs first on the session ctx, small budgets later: both orders are covered
+        for k, (mode, log_bytes, lanes, bits2) in enumerate(regimes):
+            cx = ctx if k % 2 == 0 else c2
+            if bits2 is not None:
+                os.environ["LT_LOG_BITS2"] = bits2
+            try:
+                prob.apply(cx, "u64fx"); cx.set_tally_mode(mode, log_bytes); cx.set_overlap(lanes)
+                cx.launch(n, seed=5); cx.sync()
+            finally:
+                os.environ.pop("LT_LOG_BITS2", None)
+            grids[(mode, log_bytes, lanes, bits2)] = (cx.read_grid_raw(), cx.read_counters())
+            info = cx.last_log_info()
+            if mode == "atomic":
+                assert info is None
+                continue
+            assert info["lanes"] == lanes and info["records"] + info["overflow_records"] > 50 * n
+            if log_bytes == 8 << 30:
+                assert info["overflow_records"] == 0 and info["batches"] <= (2 if lanes == 1 else 10)   # (+ the pilot)
+            if log_bytes == 48 << 20:
+                assert info["batches"] >= 4, info
+            if log_bytes == 4 << 20:
+                assert info["overflow_records"] > info["records"], info       # most deposits took the atomic fallback
+        c2.close()
+        ref, cref = grids[("atomic", 0, 1, None)]
         for k, (g, c) in grids.items():
             assert np.array_equal(g, ref), k
             assert c["steps"] == cref["steps"] and c["photons"] == n
+        ctx.set_overlap(0)
         for dtype in ("f64", "f32"):
             prob.apply(ctx, dtype); ctx.set_tally_mode("atomic"); ctx.launch(n, seed=5, f32_walk=dtype == "f32"); ctx.sync()
             a = ctx.read_grid()
-            prob.apply(ctx, dtype); ctx.set_tally_mode("log", 8 << 30); ctx.launch(n, seed=5, f32_walk=dtype == "f32"); ctx.sync()
-            b = ctx.read_grid()
-            tol = 1e-11 if dtype == "f64" else 2e-3   # f32 sums of ~1e-2 deposits onto ~2e3: order matters at 1e-3
-            assert np.abs(a - b).max() <= tol * a.max()
+            for lanes in (1, 2):
+                prob.apply(ctx, dtype); ctx.set_tally_mode("log", 8 << 30); ctx.set_overlap(lanes)
+                ctx.launch(n, seed=5, f32_walk=dtype == "f32"); ctx.sync()
+                b = ctx.read_grid()
+                tol = 1e-11 if dtype == "f64" else 2e-3   # f32 sums of ~1e-2 deposits onto ~2e3: order matters at 1e-3
+                assert np.abs(a - b).max() <= tol * a.max()
+            ctx.set_overlap(0)
     ctx.set_tally_mode("auto", 0)
+
+
+def test_config5_geometry_512_cubed(ctx):
+    """BASELINE config 5 at its own shape: two-layer skin model on a 512^3 grid of 0.025 mm voxels (16384 tiles:
+    two-pass partition with 128 level-1 bins, tile counting, 1 GiB of u64 tally).  (a) <= 2e4 photons: fixed-point
+    grid and step count equal the CPU oracle's bit for bit; (b) 2e6 photons: log == atomic bit for bit, one lane ==
+    two lanes, energy conservation, one launch == three ragged shards; the photon ids of (b) are those a rank of the
+    8-GPU run would trace (offset 3 * 1.25e7)."""
+    prob = S.two_layer(n=512, voxel=0.025)
+    n = 20000
+    prob.apply(ctx, "u64fx"); ctx.set_tally_mode("log")
+    ctx.launch(n, seed=11); ctx.sync()
+    fx, c = ctx.read_grid_raw(), ctx.read_counters()
+    assert ctx.last_log_info() is not None
+    _, fxo, co = prob.oracle().run(n, seed=11, threads=8, want_fx=True, want_f64=False)
+    check_counters(c, co, n)
+    assert np.array_equal(fx, fxo) and fx.sum() > 0
+    del fxo
+    n, off = 2 * 10 ** 6, 3 * 12500000
+    grids = {}
+    for mode, lanes in (("atomic", 1), ("log", 1), ("log", 2)):
+        prob.apply(ctx, "u64fx"); ctx.set_tally_mode(mode); ctx.set_overlap(lanes)
+        ctx.launch(n, seed=12, photon_offset=off); ctx.sync()
+        grids[(mode, lanes)] = (ctx.read_grid_raw(), ctx.read_counters())
+        if mode == "log":
+            info = ctx.last_log_info()
+            assert info["lanes"] == lanes and info["overflow_records"] == 0, info
+    ref, cref = grids[("atomic", 1)]
+    assert cref["photons"] == n and abs(O.conservation_residual(cref)) < 1e-9 * n
+    assert abs(float(ref.sum()) / O.FX_SCALE - cref["w_absorbed"]) < 1e-6 * n
+    for k, (g, c) in grids.items():
+        assert np.array_equal(g, ref), k
+        assert c["steps"] == cref["steps"]
+    del grids
+    ctx.set_tally_mode("log"); ctx.set_overlap(0); ctx.zero_tally()
+    for o2, cnt in ((0, 345678), (345678, 1000001), (1345679, n - 1345679)):
+        ctx.launch(cnt, seed=12, photon_offset=off + o2)
+    ctx.sync()
+    assert np.array_equal(ctx.read_grid_raw(), ref) and ctx.read_counters()["steps"] == cref["steps"]
+    ctx.set_tally_mode("auto", 0)
+    ctx.set_grid((8, 8, 8), (0, 0, 0), (1, 1, 1), "f64")     # release the 1 GiB grid of the session ctx
 
 
 # ---------------------------------------------------------------- several jobs in flight on one GPU
