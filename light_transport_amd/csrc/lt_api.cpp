@@ -109,7 +109,7 @@ struct lt_ctx {
     // device buffers
     DevBuf d_media[2], d_zb[2], d_lm, d_tris[2], d_nodes[2];  // [0]=f64, [1]=f32
     DevBuf d_grid, d_counters, d_head, d_table, d_scratch_in, d_scratch_out, d_scratch_aux;
-    DevBuf d_mats, d_lights, d_r0, d_r1, d_lc, d_img, d_xy, d_vtx, d_vcnt, d_clear, d_job;
+    DevBuf d_mats, d_lights, d_r0, d_r1, d_lc, d_img, d_xy, d_vtx, d_vcnt, d_clear, d_job, d_grid1;   // d_grid1: lane 1's private grid
     int cn[3] = {0, 0, 0};
     double corg[3] = {0, 0, 0}, ccell[3] = {1, 1, 1};
     bool have_clear = false;
@@ -355,14 +355,14 @@ hipError_t ensure_lane(lt_ctx* c, LogLane& ln, size_t want, size_t limit, const 
     const size_t nt = G.n_tiles, n_hist = G.bits2 ? G.nb1 : G.n_tiles;     // bins of the first partition pass
     if ((e = ln.meta.ensure(LM_WORDS * 4)) != hipSuccess) return e;
     if ((e = ln.head.ensure(sizeof(unsigned long long))) != hipSuccess) return e;
-    if ((e = ln.hist.ensure(nt * (G.bits2 ? 1 : kLogGroups) * 4)) != hipSuccess) return e;
+    if ((e = ln.hist.ensure(nt * kLogGroups * 4)) != hipSuccess) return e;
     if ((e = ln.hist1.ensure((size_t)G.nb1 * kLogGroups * 4)) != hipSuccess) return e;
     if ((e = ln.bin_base.ensure(((size_t)G.nb1 + 1) * 4)) != hipSuccess) return e;
     if ((e = ln.bin_cnt.ensure(((size_t)G.nb1 + 1) * 4)) != hipSuccess) return e;
     if ((e = ln.tile_base.ensure((nt + 1) * 4)) != hipSuccess) return e;
     if ((e = ln.tile_cnt.ensure((nt + 1) * 4)) != hipSuccess) return e;
     if ((e = ln.cursor1.ensure(n_hist * kLogGroups * 4)) != hipSuccess) return e;
-    if ((e = ln.cursor2.ensure(nt * 4)) != hipSuccess) return e;
+    if ((e = ln.cursor2.ensure(nt * kLogGroups2 * 4)) != hipSuccess) return e;
     if ((e = ln.items2.ensure(((size_t)G.nb1 + 1) * 4)) != hipSuccess) return e;
     if ((e = ln.items_c.ensure(((size_t)G.nb1 + 1) * 4)) != hipSuccess) return e;
     return ln.items_r.ensure((nt + 1) * 4);
@@ -380,7 +380,10 @@ int plan_log(lt_ctx* c, uint64_t n, int lanes, LogPlan* plan)
     if (per_lane < 16 * (size_t)kLogChunk) return c->fail(LT_E_INVALID, "lt_launch: log budget too small (%zu bytes)", c->log_budget);
     // no measurement yet (pilot or tiny launch): tissue-like media give 100-400 records per photon
     const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 400.0;
-    int sub = 8;    // overlapped launches: sub-batches per launch (the last one's reduction has nothing to hide under)
+    // overlapped launches: sub-batches per launch.  Every batch ends in a drain of its longest photons and the last
+    // one's reduction has nothing to hide under: 4 measured best on C2 and on the 512^3 share (2: 43.2, 4: 41.9,
+    // 8: 46.9, 16: 57 ms per C2 job)
+    int sub = 4;
     if (const char* e = std::getenv("LT_OVERLAP_BATCHES")) { int v = std::atoi(e); if (v >= 2 && v <= 256) sub = v; }
     const uint64_t b_target = lanes == 1 ? n : (n + (uint64_t)sub - 1) / (uint64_t)sub;
     // every resident walk wave holds one partly filled chunk: that many chunks are claimed on top of the records' own
@@ -469,11 +472,18 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
     if (resident <= 0) return c->fail(LT_E_HIP, "lt_launch: log-mode kernel not resident");
     // two lanes: each walk takes half of the resident workgroups, so that two walks together fill the register file
     // and one walk leaves room for the other lane's partition / reduce workgroups
-    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (plan.lanes == 2 ? (resident + 1) / 2 : resident);
+    int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (plan.lanes == 2 ? (resident + 1) / 2 : resident);
+    if (plan.lanes == 2) if (const char* e = std::getenv("LT_OVERLAP_WALK_BPC")) { int v_ = std::atoi(e); if (v_ >= 1 && v_ <= 8) per_cu = v_; }
     const unsigned long long cap = (unsigned long long)per_cu * (unsigned long long)c->prop.multiProcessorCount;
     if (plan.lanes == 2) {
+        // lane 1 tallies into a grid of its own (zeroed here, added to the ctx grid at the join): both lanes can then
+        // update "their" voxels with plain read-add-writes, and a walk's overflow atomics never race with the other
+        // lane's reduce
+        const size_t gb = c->n_vox() * c->grid_elem();
+        HIP_TRY(c, c->d_grid1.ensure(gb));
         HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->lanes[1].stream, c->ev_fork, 0));
+        HIP_TRY(c, hipMemsetAsync(c->d_grid1.p, 0, gb, c->lanes[1].stream));
     }
     for (const auto& bt : plan.batches) {
         LogLane& ln = c->lanes[bt.first];
@@ -481,6 +491,7 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         uint32_t* meta = (uint32_t*)ln.meta.p;
         WalkParams P = R.P;
         P.n_photons = bt.second; P.photon_offset = offset;
+        if (bt.first == 1) P.grid = c->d_grid1.p;      // (the log's overflow path adds to the lane's grid)
         P.head = (unsigned long long*)ln.head.p;
         P.log_idx = (uint32_t*)ln.log_idx.p; P.log_val = ln.log_val.p; P.log_fill = (uint32_t*)ln.log_fill.p;
         P.log_next = meta + LM_NEXT; P.log_overflow = meta + LM_OVERFLOW; P.log_cap_chunks = plan.cap_chunks[bt.first];
@@ -502,13 +513,14 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         L.itab = (uint32_t*)ln.itab.p;
         L.meta = meta; L.job = (unsigned long long*)c->d_job.p; L.cap_chunks = P.log_cap_chunks;
         L.n_tiles = G.n_tiles; L.bits2 = G.bits2;
-        L.grid = c->d_grid.p; L.n_vox = c->n_vox(); L.tally = c->tally;
+        L.grid = bt.first == 1 ? c->d_grid1.p : c->d_grid.p; L.n_vox = c->n_vox(); L.tally = c->tally;
         L.nx = (uint32_t)c->nx; L.ny = (uint32_t)c->ny; L.nz = (uint32_t)c->nz; L.ntx = G.ntx; L.nty = G.nty;
-        L.flush_atomic = plan.lanes == 2 ? 1 : 0;
+        L.flush_atomic = 0;
 
         HIP_TRY(c, hipMemsetAsync(ln.head.p, 0, sizeof(unsigned long long), s));
         HIP_TRY(c, hipMemsetAsync(meta, 0, LM_WORDS * 4, s));
-        HIP_TRY(c, hipMemsetAsync(ln.hist.p, 0, (size_t)G.n_tiles * (G.bits2 ? 1 : kLogGroups) * 4, s));
+        HIP_TRY(c, hipMemsetAsync(ln.hist.p, 0, (size_t)G.n_tiles * (G.bits2 ? kLogGroups2 : kLogGroups) * 4, s));
+        HIP_TRY(c, hipMemsetAsync(ln.log_fill.p, 0, (size_t)P.log_cap_chunks * 4, s));   // unclaimed chunk indices read as empty
         if (G.bits2) HIP_TRY(c, hipMemsetAsync(ln.hist1.p, 0, (size_t)G.nb1 * kLogGroups * 4, s));
         HIP_TRY(c, lane_event(ln, s));
         HIP_TRY(c, launch_walk(P, R.v, cfg, s));
@@ -528,6 +540,7 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
     if (plan.lanes == 2) {
         HIP_TRY(c, hipEventRecord(c->lanes[1].ev_done, c->lanes[1].stream));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->lanes[1].ev_done, 0));
+        HIP_TRY(c, launch_grid_add(c->d_grid.p, c->d_grid1.p, c->tally, c->n_vox(), c->stream));
     }
     return LT_OK;
 }
@@ -616,7 +629,7 @@ int lt_destroy(lt_ctx* c)
     c->d_scratch_in.release(); c->d_scratch_out.release(); c->d_scratch_aux.release();
     c->d_mats.release(); c->d_lights.release(); c->d_r0.release(); c->d_r1.release(); c->d_lc.release();
     c->d_img.release(); c->d_xy.release(); c->d_vtx.release(); c->d_vcnt.release(); c->d_clear.release();
-    c->d_job.release();
+    c->d_job.release(); c->d_grid1.release();
     if (c->lanes[1].stream) (void)hipStreamSynchronize(c->lanes[1].stream);
     for (int k = 0; k < 2; k++) {
         c->lanes[k].release_all();

@@ -563,11 +563,11 @@ LT_DEV void emit_deposit(const WalkParams& P, bool has, unsigned idx, typename T
     const unsigned cnt = (unsigned)__popcll(m);
     if (lg_end - lg_cur < cnt) {
         const int lane = threadIdx.x & 63;
-        if (lg_chunk != 0xffffffffu && lane == 0)
-            P.log_fill[lg_chunk] = (lg_cur - lg_chunk * kLogChunk) | ((blockIdx.x & (kLogGroups - 1)) << 24);
+        const unsigned grp = blockIdx.x & (kLogGroups - 1);
+        if (lg_chunk != 0xffffffffu && lane == 0) P.log_fill[lg_chunk] = lg_cur - lg_chunk * kLogChunk;
         unsigned c = 0;
-        if (lane == 0) c = __hip_atomic_fetch_add(P.log_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c = __builtin_amdgcn_readfirstlane(c);
+        if (lane == 0) c = __hip_atomic_fetch_add(P.log_next + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c = grp + kLogGroups * __builtin_amdgcn_readfirstlane(c);     // the group's own chunks: see kLogGroups
         if (c < P.log_cap_chunks) { lg_chunk = c; lg_cur = c * kLogChunk; lg_end = lg_cur + kLogChunk; }
         else { lg_chunk = 0xffffffffu; lg_cur = lg_end = 0; }
     }
@@ -811,6 +811,24 @@ __global__ void k_grid_to_f64(const void* grid, int tally, size_t n, double* out
         else if (tally == LT_TALLY_F64) out[i] = reinterpret_cast<const double*>(grid)[i];
         else out[i] = (double)reinterpret_cast<const unsigned long long*>(grid)[i] * (1.0 / LT_FX_SCALE);
     }
+}
+
+// dst += src over whole grids, 16 bytes per lane (the grids are hipMalloc'ed: 256-byte aligned).  Joins the private
+// grid of an overlapped launch's second lane into the ctx grid: HBM-bound, 3 x grid bytes.
+template <typename T>
+__global__ void __launch_bounds__(256) k_grid_add(T* __restrict__ dst, const T* __restrict__ src, size_t n)
+{
+    constexpr size_t kV = 16 / sizeof(T);
+    struct alignas(16) V { T v[kV]; };
+    const size_t nv = n / kV;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        V a = reinterpret_cast<V*>(dst)[i];
+        const V b = reinterpret_cast<const V*>(src)[i];
+#pragma unroll
+        for (size_t k = 0; k < kV; k++) a.v[k] += b.v[k];
+        reinterpret_cast<V*>(dst)[i] = a;
+    }
+    for (size_t i = nv * kV + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -1156,6 +1174,14 @@ hipError_t launch_grid_to_f64(const void* grid, int tally, size_t n, double* out
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_grid_to_f64, dim3(2048), dim3(256), 0, s, grid, tally, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_grid_add(void* dst, const void* src, int tally, size_t n, hipStream_t s)
+{
+    if (tally == LT_TALLY_F32) hipLaunchKernelGGL(k_grid_add<float>, dim3(2048), dim3(256), 0, s, (float*)dst, (const float*)src, n);
+    else if (tally == LT_TALLY_F64) hipLaunchKernelGGL(k_grid_add<double>, dim3(2048), dim3(256), 0, s, (double*)dst, (const double*)src, n);
+    else hipLaunchKernelGGL(k_grid_add<unsigned long long>, dim3(2048), dim3(256), 0, s, (unsigned long long*)dst, (const unsigned long long*)src, n);
     return hipGetLastError();
 }
 

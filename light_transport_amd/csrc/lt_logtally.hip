@@ -156,75 +156,45 @@ __device__ __forceinline__ uint32_t upper_slot(const uint32_t* prefix, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Rank of a record inside its digit, for one record slot of every lane of a wave.  A plain returning LDS atomic per
-// lane serialises on the hot digits (the records of a chunk cluster in the few tiles around the source: most lanes of
-// a wave-instruction hit the same counter).  Here the lanes that share the digit of the first active lane, and those
-// that share the digit of the first lane left after that, are counted with a ballot and added by ONE lane each; only
-// the rest add for themselves.  Issue and use are split so that the atomics of all record slots are in flight at once.
-struct RankMasks { unsigned long long m0, m1; int l0, l1; };
-
-__device__ __forceinline__ RankMasks rank_masks(uint32_t d, bool valid)
-{
-    RankMasks r; r.m0 = r.m1 = 0ull; r.l0 = r.l1 = 0;
-    const unsigned long long act = __ballot(valid);
-    if (act != 0ull) {
-        r.l0 = __ffsll((long long)act) - 1;
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, r.l0);
-        r.m0 = __ballot(valid && d == d0);
-        const unsigned long long rest = act & ~r.m0;
-        if (rest != 0ull) {
-            r.l1 = __ffsll((long long)rest) - 1;
-            const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)d, r.l1);
-            r.m1 = __ballot(valid && d == d1);
-        }
-    }
-    return r;
-}
-
-__device__ __forceinline__ uint32_t rank_issue(uint32_t* s_cnt, uint32_t d, bool valid, int lane)
-{
-    const RankMasks r = rank_masks(d, valid);
-    const bool in0 = (r.m0 >> lane) & 1ull, in1 = (r.m1 >> lane) & 1ull;
-    const bool lead0 = in0 && lane == r.l0, lead1 = in1 && lane == r.l1;
-    const uint32_t amount = lead0 ? (uint32_t)__popcll(r.m0) : (lead1 ? (uint32_t)__popcll(r.m1) : 1u);
-    uint32_t ret = 0;
-    if (lead0 || lead1 || (valid && !in0 && !in1)) ret = atomicAdd(&s_cnt[d], amount);   // one ds_add_rtn_u32
-    return ret;
-}
-
-__device__ __forceinline__ uint32_t rank_finish(uint32_t ret, uint32_t d, bool valid, int lane)
-{
-    const RankMasks r = rank_masks(d, valid);
-    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)ret, r.l0), b1 = (uint32_t)__builtin_amdgcn_readlane((int)ret, r.l1);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if ((r.m0 >> lane) & 1ull) return b0 + (uint32_t)__popcll(r.m0 & below);
-    if ((r.m1 >> lane) & 1ull) return b1 + (uint32_t)__popcll(r.m1 & below);
-    return ret;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Two-pass form: descriptor of every pass-2 work item (where its records start in pass 1's output, how many, which
-// level-1 bin), so that the partition reads ONE record per item -- an iteration ahead -- instead of searching the
-// bin prefix with dependent loads while 511 lanes wait.
+// Two-pass form: descriptor of every pass-2 work unit (up to kCountGroup x 4096 consecutive records of ONE level-1
+// bin in pass 1's output: where they start, how many, which bin), so that k_log_count2 and pass 2 read one record per
+// unit -- a unit ahead -- instead of searching the bin prefix with dependent loads while 511 lanes wait.
 __global__ void __launch_bounds__(256) k_log_items2(LogReduceParams L)
 {
     const uint32_t nb1 = (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2;
-    const uint32_t n_items = L.meta[LM_ITEMS2];
-    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < n_items; item += gridDim.x * blockDim.x) {
-        const uint32_t a = upper_slot(L.items2, nb1, item);
-        const uint32_t done = (item - L.items2[a]) * kPartItem, left = L.bin_cnt[a] - done;
-        reinterpret_cast<uint4*>(L.itab)[item] = make_uint4(L.bin_base[a] + done, left < kPartItem ? left : kPartItem, a, 0u);
+    const uint32_t n_units = L.meta[LM_ITEMS_C];
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += gridDim.x * blockDim.x) {
+        const uint32_t a = upper_slot(L.items_c, nb1, u);
+        const uint32_t done = (u - L.items_c[a]) * (kCountGroup * kPartItem), left = L.bin_cnt[a] - done;
+        reinterpret_cast<uint4*>(L.itab)[u] =
+            make_uint4(L.bin_base[a] + done, left < kCountGroup * kPartItem ? left : kCountGroup * kPartItem, a, 0u);
     }
+}
+
+// chunks of the log that may hold records: the groups claim interleaved chunk indices (group + kLogGroups * n)
+__device__ __forceinline__ uint32_t claimed_chunks(const LogReduceParams& L)
+{
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < kLogGroups; g++) {
+        const uint32_t c = L.meta[LM_NEXT + g];
+        const uint32_t top = c ? g + kLogGroups * (c - 1) + 1 : 0;
+        n = top > n ? top : n;
+    }
+    return n < L.cap_chunks ? n : L.cap_chunks;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Partition work item: <= 4096 records.  Registers hold the item (8 records per lane, loaded 16 bytes at a time), LDS
 // holds the digit histogram / offsets and the digit-sorted copy; each digit's run leaves as one contiguous write.
+// Work is strided over the grid in units of one log chunk (pass 1) / one k_log_items2 unit (pass 2): no shared work
+// counter (one word sustains only ~90 returning atomics per microsecond, less than the item rate of this kernel),
+// and a workgroup only ever serves ONE cursor group (see kLogGroups).
 // Software pipeline: the next item's loads are issued as soon as this item's records sit in LDS (their registers are
 // free then), so they fly during the write-out; the cursor atomics are issued before the digit scan and collected
 // after the LDS scatter.
 #ifndef LT_PART_WAVES
-#define LT_PART_WAVES 4
+#define LT_PART_WAVES 8
 #endif
 template <typename TV, int PASS>
 __global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogReduceParams L)
@@ -241,69 +211,71 @@ __global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogRed
     const uint32_t mask2 = (1u << L.bits2) - 1;
     const uint32_t nb = PASS == 1 ? nb1 : (1u << L.bits2);
     const bool final_pass = PASS == 2 || L.bits2 == 0;
-    // the item count lives in device memory (chunks the walk claimed / items the scan derived), so the host never has
-    // to read anything back between the kernels of a batch
-    uint32_t n_items = PASS == 1 ? L.meta[LM_NEXT] : L.meta[LM_ITEMS2];
-    if (PASS == 1) n_items = (n_items > L.cap_chunks ? L.cap_chunks : n_items) * kItemsPerChunk;
+    // the amount of work lives in device memory (chunks the walk claimed / units the scan derived), so the host never
+    // has to read anything back between the kernels of a batch
+    const uint32_t n_units = PASS == 1 ? claimed_chunks(L) : L.meta[LM_ITEMS_C];
+    constexpr uint32_t kSub = PASS == 1 ? kItemsPerChunk : kCountGroup;     // 4096-record items per unit
     const uint32_t* in_idx = PASS == 1 ? L.log_idx : L.tmp_idx;
     const TV* in_val = reinterpret_cast<const TV*>(PASS == 1 ? L.log_val : L.tmp_val);
     uint32_t* out_idx = PASS == 1 ? L.tmp_idx : const_cast<uint32_t*>(L.log_idx);
     TV* out_val = reinterpret_cast<TV*>(PASS == 1 ? L.tmp_val : const_cast<void*>(L.log_val));
     auto digit = [&](uint32_t k_) { const uint32_t t_ = tile_of(k_); return PASS == 1 ? (t_ >> L.bits2) : (t_ & mask2); };
 
-    // item descriptor: PASS 1: x = the chunk's fill word (records | group << 24); PASS 2: (start, records, bin, -)
-    auto describe = [&](uint32_t it) -> uint4 {
-        if (PASS == 1) return make_uint4(L.log_fill[it / kItemsPerChunk], 0u, 0u, 0u);
-        return reinterpret_cast<const uint4*>(L.itab)[it];
+    // unit descriptor (start, records, level-1 bin): pass 1 -- a chunk and its fill; pass 2 -- k_log_items2's table
+    auto describe = [&](uint32_t u) -> uint4 {
+        if (PASS == 1) return make_uint4(u * kLogChunk, L.log_fill[u], 0u, 0u);
+        return reinterpret_cast<const uint4*>(L.itab)[u];
     };
     uint32_t key[kPerThread], ret[kPerThread];
     TV val[kPerThread];
     // lane owns records k = g * 2048 + tid * 4 + j: 16 B of indices and 16 / 32 B of values per load group.  Groups are
     // read whole and unconditionally: the bytes behind an item's end are mapped (slack behind every buffer), and
-    // records at k >= n are masked out below.
-    auto load_item = [&](uint32_t lo_) {
+    // records at k >= n are masked out below.  Indices are requested an item ahead; values only after the ranking (they
+    // are first needed at the LDS scatter), which keeps the kernel within 64 VGPRs: four waves per SIMD beside a walk.
+    auto load_keys = [&](uint32_t lo_) {
 #pragma unroll
         for (int g = 0; g < kPerThread / 4; g++) {
-            const uint32_t k = (uint32_t)g * (kPartThreads * 4) + threadIdx.x * 4;
-            const uint4 q = *reinterpret_cast<const uint4*>(in_idx + lo_ + k);
-            const Quad<TV> v = *reinterpret_cast<const Quad<TV>*>(in_val + lo_ + k);
+            const uint4 q = *reinterpret_cast<const uint4*>(in_idx + lo_ + (uint32_t)g * (kPartThreads * 4) + threadIdx.x * 4);
             key[4 * g] = q.x; key[4 * g + 1] = q.y; key[4 * g + 2] = q.z; key[4 * g + 3] = q.w;
+        }
+    };
+    auto load_vals = [&](uint32_t lo_) {
+#pragma unroll
+        for (int g = 0; g < kPerThread / 4; g++) {
+            const Quad<TV> v = *reinterpret_cast<const Quad<TV>*>(in_val + lo_ + (uint32_t)g * (kPartThreads * 4) + threadIdx.x * 4);
 #pragma unroll
             for (int j = 0; j < 4; j++) val[4 * g + j] = v.v[j];
         }
     };
 
-    // equal-sized work items, strided over the grid: no shared work counter -- one word sustains only ~90 returning
-    // atomics per microsecond, less than the item rate of this kernel
-    uint32_t item = blockIdx.x;
-    if (item >= n_items) return;
-    uint4 ds = describe(item);
-    load_item(PASS == 1 ? item * kPartItem : ds.x);
-  for (; item < n_items; item += gridDim.x) {
-    const uint32_t next = item + gridDim.x;
-    for (uint32_t d = threadIdx.x; d < nb + 2; d += kPartThreads) s_a[d] = 0;
-    uint32_t n, cstride;
+    uint32_t unit = blockIdx.x, sub = 0;
+    if (unit >= n_units) return;
+    uint4 ds = describe(unit);
+    uint4 dsn = unit + gridDim.x < n_units ? describe(unit + gridDim.x) : make_uint4(0u, 0u, 0u, 0u);
+    load_keys(ds.x);
+  for (;;) {
+    // this item: records [ds.x + sub * 4096, ...) of the unit; the one after it
+    const uint32_t off = sub * kPartItem;
+    const uint32_t n = ds.y > off ? (ds.y - off < kPartItem ? ds.y - off : kPartItem) : 0;
+    const bool more_here = sub + 1 < kSub && ds.y > off + kPartItem;
+    const bool have_next = more_here || unit + gridDim.x < n_units;
+    const uint32_t next_lo = more_here ? ds.x + off + kPartItem : dsn.x;
     uint32_t* cursor;
-    if (PASS == 1) {
-        const uint32_t fill = ds.x & kFillMask, part = (item % kItemsPerChunk) * kPartItem;
-        n = fill > part ? (fill - part < kPartItem ? fill - part : kPartItem) : 0;
-        cursor = L.cursor1 + (ds.x >> 24); cstride = kLogGroups;       // the cursors of the chunk's group
-    } else {
-        n = ds.y;
-        cursor = L.cursor2 + (ds.z << L.bits2); cstride = 1;
-    }
+    uint32_t cstride;
+    if (PASS == 1) { cursor = L.cursor1 + (unit & (kLogGroups - 1)); cstride = kLogGroups; }        // the cursors of the chunk's group
+    else { cursor = L.cursor2 + ((size_t)(ds.z << L.bits2) * kLogGroups2 + (unit & (kLogGroups2 - 1))); cstride = kLogGroups2; }
+    if (n != 0) {
+    for (uint32_t d = threadIdx.x; d < nb + 2; d += kPartThreads) s_a[d] = 0;
     __syncthreads();
-    // ---- rank inside the digit
+    // ---- rank inside the digit: one returning LDS atomic per record.  (Counting the lanes that share the first
+    //      lane's digit with a ballot and adding once for all of them removes the same-address serialisation of the
+    //      hot digits but costs ~150 instructions per record slot: measured slower, alone and beside a walk.)
 #pragma unroll
     for (int r = 0; r < kPerThread; r++) {
         const uint32_t k = (uint32_t)(r >> 2) * (kPartThreads * 4) + threadIdx.x * 4 + (r & 3);
-        ret[r] = rank_issue(s_a, digit(key[r]), k < n, lane);
+        ret[r] = k < n ? atomicAdd(&s_a[digit(key[r])], 1u) : 0u;
     }
-#pragma unroll
-    for (int r = 0; r < kPerThread; r++) {
-        const uint32_t k = (uint32_t)(r >> 2) * (kPartThreads * 4) + threadIdx.x * 4 + (r & 3);
-        ret[r] = rank_finish(ret[r], digit(key[r]), k < n, lane);
-    }
+    load_vals(ds.x + off);     // in flight during the scan
     __syncthreads();
     // ---- space for every non-empty digit: one returning global atomic each, issued before the scan so that its
     //      latency runs under the scan and the LDS scatter
@@ -316,7 +288,7 @@ __global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogRed
         // ---- exclusive prefix over the digits, in place: two digits per lane, wave scan, wave totals through LDS
         incl = c0 + c1;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        for (int off2 = 1; off2 < 64; off2 <<= 1) { const uint32_t o = __shfl_up(incl, off2, 64); if (lane >= off2) incl += o; }
         if (lane == 63) s_wsum[wave] = incl;
     }
     __syncthreads();
@@ -340,10 +312,7 @@ __global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogRed
         }
     }
     // ---- the registers are free: request the next item now, it arrives during the write-out
-    if (next < n_items) {
-        ds = describe(next);
-        load_item(PASS == 1 ? next * kPartItem : ds.x);
-    }
+    if (have_next) load_keys(next_lo);
     {
         const uint32_t d = 2 * threadIdx.x;
         if (c0) s_b[d] = g0 - ex;
@@ -365,6 +334,13 @@ __global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogRed
         }
     }
     __syncthreads();   // LDS is reused by the next item
+    } else if (have_next) load_keys(next_lo);     // an empty item (a chunk nobody claimed, a short last chunk)
+    if (!have_next) break;
+    if (more_here) sub++;
+    else {
+        unit += gridDim.x; sub = 0; ds = dsn;
+        if (unit + gridDim.x < n_units) dsn = describe(unit + gridDim.x);
+    }
   }
 }
 
@@ -375,20 +351,14 @@ __global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogRed
 __global__ void __launch_bounds__(kPartThreads) k_log_count2(LogReduceParams L)
 {
     __shared__ uint32_t s_cnt[1u << kMaxBits2];
-    __shared__ uint32_t s_range[3];
-    const uint32_t nb1 = (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2, mask2 = (1u << L.bits2) - 1;
-    const uint32_t n_items = L.meta[LM_ITEMS_C];
+    const uint32_t mask2 = (1u << L.bits2) - 1;
+    const uint32_t n_units = L.meta[LM_ITEMS_C];
     const int lane = threadIdx.x & 63;
-  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-    if (threadIdx.x == 0) {
-        const uint32_t a = upper_slot(L.items_c, nb1, item);
-        const uint32_t done = (item - L.items_c[a]) * (kCountGroup * kPartItem), left = L.bin_cnt[a] - done;
-        s_range[0] = L.bin_base[a] + done; s_range[1] = left < kCountGroup * kPartItem ? left : kCountGroup * kPartItem;
-        s_range[2] = a;
-    }
+  for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    const uint4 ds = reinterpret_cast<const uint4*>(L.itab)[unit];
     if (threadIdx.x < (1u << kMaxBits2)) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t lo = s_range[0], n = s_range[1], bin = s_range[2];
+    const uint32_t lo = ds.x, n = ds.y, bin = ds.z;
     for (uint32_t k = threadIdx.x * 4; k < n; k += kPartThreads * 4) {    // lo is a multiple of 4: aligned 16-byte loads
         const uint4 q = *reinterpret_cast<const uint4*>(L.tmp_idx + lo + k);
         const uint32_t kk[4] = {q.x, q.y, q.z, q.w};
@@ -410,7 +380,8 @@ __global__ void __launch_bounds__(kPartThreads) k_log_count2(LogReduceParams L)
     __syncthreads();
     if (threadIdx.x < (1u << L.bits2)) {
         const uint32_t t = (bin << L.bits2) + threadIdx.x, v = s_cnt[threadIdx.x];
-        if (v && t < L.n_tiles) __hip_atomic_fetch_add(&L.hist[t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v && t < L.n_tiles)       // the unit's group: the cursors pass 2 will use for this unit (see kLogGroups)
+            __hip_atomic_fetch_add(&L.hist[t * kLogGroups2 + (unit & (kLogGroups2 - 1))], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
   }
@@ -504,7 +475,7 @@ uint32_t log_part_item() { return kPartItem; }
 hipError_t launch_log_scan_tiles(const LogReduceParams& L, hipStream_t s)
 {
     // one-pass form: the only partition pass is the final one and runs on cursor1
-    hipLaunchKernelGGL(k_log_scan_tiles, dim3(1), dim3(kScanThreads), 0, s, L.hist, L.bits2 ? 1u : kLogGroups, L.tile_base, L.tile_cnt,
+    hipLaunchKernelGGL(k_log_scan_tiles, dim3(1), dim3(kScanThreads), 0, s, L.hist, L.bits2 ? kLogGroups2 : kLogGroups, L.tile_base, L.tile_cnt,
                        L.bits2 ? L.cursor2 : L.cursor1, L.items_r, L.meta, L.job, L.n_tiles);
     return hipGetLastError();
 }
@@ -554,15 +525,16 @@ template <int PASS> static hipError_t launch_part(const LogReduceParams& L, hipS
 hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s) { return launch_part<1>(L, s); }
 hipError_t launch_log_part2(const LogReduceParams& L, hipStream_t s)
 {
-    // tiles of pass 1's output are counted first: the scan of those counts places pass 2's output
+    // work units of pass 2, then the tiles of pass 1's output are counted per unit group: the scan of those counts
+    // places pass 2's output
+    hipLaunchKernelGGL(k_log_items2, dim3(256), dim3(256), 0, s, L);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
     static std::atomic<unsigned> blocks{0};
     const void* fn = reinterpret_cast<const void*>(&k_log_count2);
     hipLaunchKernelGGL(k_log_count2, dim3(persistent_blocks(blocks, fn, kPartThreads, 0)), dim3(kPartThreads), 0, s, L);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if ((e = launch_log_scan_tiles(L, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_log_items2, dim3(1024), dim3(256), 0, s, L);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = launch_log_scan_tiles(L, s)) != hipSuccess) return e;
     return launch_part<2>(L, s);
 }
 
