@@ -1,34 +1,40 @@
 #!/usr/bin/env python3
 """Headline benchmark of the photon-transport hot path (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one complete job of config C2 on every rank: zero the tally, trace
-1e7 photons (homogeneous semi-infinite slab mu_a=0.1 mu_s=10 g=0.9 n=1, 256^3 grid
-of 0.1 mm voxels, pencil beam, f64 walk, XORWOW, f64 tally; deposits go through
-the log-structured tally: walk -> deposit log -> tile partition -> LDS reduce) and
--- for N > 1 -- sum-reduce the voxel grid + counters to rank 0 with RCCL.  Ranks trace disjoint
-photon-id ranges (weak scaling: 1e7 photons per GPU); there is no other
-collective.  Inputs are synthetic by nature (the scene is ~100 bytes of constants,
-resident in HBM before the timed region).  By default two jobs are in flight per
-GPU (after a short untimed probe has confirmed that they overlap; --inflight 2
-forces it, --inflight 1 forbids it: two contexts, i.e. two HIP streams with their own grid and
-deposit log, take the steps in turn), so that the bandwidth-bound log reduction of
-one job runs beside the VALU-bound walk of the next; every step is still a
-complete job and all K of them finish inside the timed region.
+One "step" = one complete job on every rank: zero the tally, trace the workload's photons (f64 walk, XORWOW, f64 tally;
+deposits go through the log-structured tally: walk -> deposit log -> tile partition -> LDS reduce) and -- for N > 1 --
+sum-reduce the voxel grid + counters to rank 0 with RCCL, enqueued on the job's own stream.  Ranks trace disjoint
+photon-id ranges (weak scaling); there is no other collective.  Inputs are synthetic by nature (the scene is ~100 bytes
+of constants, resident in HBM before the timed region).
+
+Workloads (BASELINE.json configs):
+  c2 (default)  1e7 photons per GPU, homogeneous semi-infinite slab, 256^3 grid -- the config the metric is quoted on
+  c5            1.25e7 photons per GPU (the per-GPU share of 1e8 over 8), two-layer skin model, 512^3 grid (1 GiB f64)
+
+Regimes (how a rank keeps its GPU busy; results are identical):
+  one_call      ONE context; every lt_launch is cut into sub-batches that alternate between the context's two lanes, so
+                that one batch's log reduction runs beside the next batch's walk (lt_set_overlap 2)      [--inflight 1]
+  two_jobs      TWO contexts take the steps in turn (two complete jobs in flight)                         [--inflight 2]
+  one_at_a_time ONE context, one lane: kernels strictly back to back                        [--inflight 1 --overlap 1]
+By default a short untimed probe runs all three and the timed region uses the fastest; the probe's numbers are reported.
 
 Prints ONE JSON line on rank 0:  metric = photon-steps/s over all ranks, plus
-  roofline      algorithmic tally bytes (16 B per photon-step for the f64 tally:
-                8 B read + 8 B write of one voxel) per launch / the time the device
-                takes per launch (wall / K with jobs in flight; the job's event time
-                with --inflight 1), against the 8 TB/s HBM peak; per-kernel
-                durations from HIP events on each ctx's own stream;
-  cpu_baseline  the CPU oracle (oracle/, a port -- the reference has no such
-                path) on all host cores on a bounded sample of the same workload.
+  roofline      algorithmic tally bytes (16 B per photon-step for the f64 tally: 8 B read + 8 B write of one voxel)
+                per launch / the time the device takes per launch, against the 8 TB/s HBM peak; per-kernel durations of
+                one job alone on the device (HIP events on the ctx stream) with their own fractions; measured HBM
+                traffic (rocprofv3 PMC passes, profiles/traffic.json -- only if taken on these very kernel sources);
+  readback      D2H of the grid into pinned host memory, and the readback-inclusive rate;
+  cpu_baseline  the CPU oracle (oracle/, a port -- the reference has no such path) on the host cores on a bounded
+                sample of the same workload.
 """
 import argparse
+import glob
+import hashlib
+import importlib
 import json
 import os
 import sys
@@ -38,25 +44,43 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# Jobs in flight need their streams on DIFFERENT hardware queues: the HIP runtime multiplexes a process's streams
-# onto GPU_MAX_HW_QUEUES (default 4) queues, and once torch + RCCL have taken theirs two contexts can end up sharing
-# one, which serialises their kernels (measured: 57 instead of 39 ms per step under torch.distributed.run).  Must be
-# set before the runtime initialises, i.e. before torch is imported.
+# Jobs / lanes in flight need their streams on DIFFERENT hardware queues: the HIP runtime multiplexes a process's
+# streams onto GPU_MAX_HW_QUEUES (default 4) queues, and once torch + RCCL have taken theirs two streams can end up
+# sharing one, which serialises their kernels (measured: 57 instead of 39 ms per step under torch.distributed.run).
+# Must be set before the runtime initialises, i.e. before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-N_PHOTONS = 10 ** 7
-GRID_N, VOXEL = 256, 0.1
-MEDIUM = (0.1, 10.0, 0.9, 1.0)
+INF = float("inf")
+WORKLOADS = {
+    "c2": dict(photons=10 ** 7, grid=256, voxel=0.1, media=[(0.1, 10.0, 0.9, 1.0)], z_bounds=[0.0, INF], medium_idx=[0],
+               text="C2: %.0e photons per GPU, homogeneous semi-infinite slab (mu_a=0.1, mu_s=10, g=0.9, n=1), %d^3 voxel grid "
+                    "(%.3g mm), pencil beam"),
+    "c5": dict(photons=12500000, grid=512, voxel=0.025, media=[(0.43, 10.7, 0.79, 1.5), (0.27, 18.7, 0.82, 1.4)],
+               z_bounds=[0.0, 0.1, INF], medium_idx=[0, 1],
+               text="C5 per-GPU share: %.3g photons per GPU (1e8 over 8 GPUs), two-layer skin model (epidermis 0.1 mm n=1.5 / "
+                    "dermis n=1.4, air above), %d^3 voxel grid (%.3g mm), pencil beam"),
+}
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_STEP = {"f32": 8, "f64": 16, "u64fx": 16}
+REC_VALUE_BYTES = {"f32": 4, "f64": 8, "u64fx": 8}
 
 
-def configure(ctx, tally):
-    half = GRID_N * VOXEL / 2
-    ctx.set_media([MEDIUM])
-    ctx.set_layers([0.0, np.inf], [0], 1.0, 1.0)
-    ctx.set_grid((GRID_N,) * 3, (-half, -half, 0.0), (VOXEL,) * 3, tally)
+def configure(ctx, wl, tally):
+    half = wl["grid"] * wl["voxel"] / 2
+    ctx.set_media(wl["media"])
+    ctx.set_layers(wl["z_bounds"], wl["medium_idx"], 1.0, 1.0)
+    ctx.set_grid((wl["grid"],) * 3, (-half, -half, 0.0), (wl["voxel"],) * 3, tally)
     ctx.set_source(0, (0.0, 0.0, 0.0), (0.0, 0.0, 1.0))
+
+
+def kernel_sources_sha():
+    """Identity of the kernel sources a PMC pass was taken on (profiles/traffic.json carries the same hash)."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "light_transport_amd", "csrc", "*.[hic]*")) + [os.path.join(ROOT, "include", "lt.h")]):
+        if f.endswith(".o"):
+            continue
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def effective_cores():
@@ -78,48 +102,90 @@ def effective_cores():
     return n
 
 
-def cpu_baseline(target_seconds=12.0):
-    """CPU oracle (port) on every host core, bounded sample of C2."""
+def cpu_baseline(wl, wl_name, target_seconds=12.0):
+    """CPU oracle (port) on every host core, bounded sample of the workload."""
     from oracle import oracle as O
     cores = effective_cores()
-    half = GRID_N * VOXEL / 2
-    sc = O.OracleScene([MEDIUM], (GRID_N,) * 3, (-half, -half, 0.0), (VOXEL,) * 3,
-                       layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))
+    half = wl["grid"] * wl["voxel"] / 2
+    sc = O.OracleScene(wl["media"], (wl["grid"],) * 3, (-half, -half, 0.0), (wl["voxel"],) * 3,
+                       layers=dict(z_bounds=wl["z_bounds"], medium_idx=wl["medium_idx"]))
     t0 = time.perf_counter()
     _, _, c = sc.run(50000, seed=0, threads=cores)
     probe = time.perf_counter() - t0
-    rate = c["steps"] / probe
-    n = int(min(N_PHOTONS, max(100000, target_seconds * rate / 281.0)))
+    rate, per_photon = c["steps"] / probe, c["steps"] / 50000.0
+    n = int(min(wl["photons"], max(100000, target_seconds * rate / per_photon)))
     t0 = time.perf_counter()
     _, _, c = sc.run(n, seed=0, threads=cores)
     dt = time.perf_counter() - t0
     return {"value": c["steps"] / dt, "unit": "photon-steps/s", "cores": cores, "kind": "port",
-            "sample": "first %d photons of the same C2 workload (f64, 256^3 f64 grid), %.1f s wall, pthreads" % (n, dt),
+            "sample": "first %d photons of the same %s workload (f64, %d^3 f64 grid), %.1f s wall, pthreads" % (
+                n, wl_name.upper(), wl["grid"], dt),
             "photons_per_sec": n / dt}
 
 
-def main():
+class Device:
+    """torch plumbing of a real run: device selection, synchronisation, scalars for the rank agreement."""
+    name = "cuda"
+
+    def __init__(self, local_rank):
+        import torch
+        self.torch = torch
+        torch.cuda.set_device(local_rank)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def scalar(self, v, dtype):
+        return self.torch.tensor([v], dtype=dtype, device="cuda")
+
+    def host_buffer(self, nbytes):
+        return self.torch.empty(nbytes, dtype=self.torch.uint8, pin_memory=True).numpy()
+
+
+class HostDevice(Device):
+    """Stand-in used by the CPU test of the N > 1 control flow (gloo, recording contexts): no GPU is touched."""
+    name = "cpu"
+
+    def __init__(self, local_rank):
+        import torch
+        self.torch = torch
+
+    def sync(self):
+        pass
+
+    def scalar(self, v, dtype):
+        return self.torch.tensor([v], dtype=dtype)
+
+    def host_buffer(self, nbytes):
+        return np.empty(nbytes, dtype=np.uint8)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--photons", type=int, default=N_PHOTONS, help="photons per GPU per step (default: C2's 1e7)")
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--photons", type=int, default=0, help="photons per GPU per step (default: the workload's)")
     ap.add_argument("--tally", default="f64", choices=["f32", "f64", "u64fx"])
     ap.add_argument("--f32-walk", action="store_true", help="f32 walk arithmetic (default f64, the reference's dtype)")
-    ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--tally-mode", default="log", choices=["log", "atomic", "auto"],
                     help="log: deposit log + tile partition + LDS reduce (default); atomic: one global atomic per deposit")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="jobs in flight per GPU (contexts taking the steps in turn); 1 = strictly one job at a time; "
-                         "0 (default) = 2 if a short untimed probe confirms that two jobs overlap on this device, else 1")
+                    help="contexts taking the steps in turn: 2 = two jobs in flight, 1 = one context; 0 (default) = an "
+                         "untimed probe picks the fastest regime")
+    ap.add_argument("--overlap", type=int, default=-1,
+                    help="lanes inside one launch (lt_set_overlap) for --inflight 1: 2 = one_call, 1 = one_at_a_time")
     ap.add_argument("--no-alone", action="store_true",
-                    help="skip the single-job reference launches after the timed region (keeps a rocprofv3 kernel "
-                         "trace of this command to launches of the timed regime only)")
+                    help="skip the single-job reference launches and the readback after the timed region (keeps a rocprofv3 "
+                         "kernel trace of this command to launches of the timed regime only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)        # tests: gloo
+    ap.add_argument("--ctx-factory", default="", help=argparse.SUPPRESS)        # tests: module:callable returning a recording ctx
+    args = ap.parse_args(argv)
+    wl = WORKLOADS[args.workload]
+    per_gpu = args.photons or wl["photons"]
 
-    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -128,80 +194,102 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and not distributed:
         raise SystemExit("for N > 1 launch through torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
+    fake = bool(args.ctx_factory)
+    dev = HostDevice(local_rank) if fake else Device(local_rank)
+    torch = dev.torch
+    dist = None
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
-    import light_transport_amd as lt
-    from light_transport_amd import distributed as ltd
-    # --inflight D: D contexts (stream + grid + deposit log each) take the steps in turn, so the bandwidth-bound log
-    # reduction of one job runs beside the VALU-bound walk of the next.  The walk is then launched at 2 workgroups per
-    # CU per job: two walks together fill the 4 waves/SIMD the register file holds, one walk leaves room for the
-    # other job's partition / reduce workgroups.
-    auto_depth = args.inflight <= 0
-    depth = 2 if auto_depth else args.inflight
+    if fake:
+        mod, attr = args.ctx_factory.split(":")
+        make_ctx = getattr(importlib.import_module(mod), attr)
+        reduce_ctx = lambda c: c.reduce_to(dist, 0)                              # noqa: E731
+    else:
+        import light_transport_amd as lt
+        from light_transport_amd import distributed as ltd
+        make_ctx = lambda: lt.Context(local_rank)                                # noqa: E731
+        reduce_ctx = lambda c: ltd.reduce_device(c, dst=0)                       # RCCL sum of grid + counters to rank 0, on the ctx stream  # noqa: E731
 
-    def walk_bpc(d):
-        return args.blocks_per_cu or ((3 if args.f32_walk else 2) if d > 1 else 0)   # f32 walk: 96 VGPRs, 5 waves/SIMD fit
-
-    def set_geometry(c, d):
-        b = walk_bpc(d)
-        c.set_launch_config(b, args.threads or (256 if b else 0))
-
-    ctxs = []
-    for _ in range(depth):
-        c = lt.Context(local_rank)
-        configure(c, args.tally)
-        c.set_tally_mode(args.tally_mode)
-        set_geometry(c, depth)
-        if args.tally_mode != "atomic":
-            c.reserve_log(args.photons)   # scratch allocation is set-up, not part of a step (matters when --warmup 0)
-        ctxs.append(c)
-    probe = None
-    if auto_depth:
-        # Untimed probe: does the device really run two jobs side by side?  (It does not when the two contexts' streams
-        # share a hardware queue, see GPU_MAX_HW_QUEUES above.)  One job at a time on ctx 0 against four jobs in turn.
-        def run_jobs(cs, n):
-            for c in cs:
-                c.sync()
-            t0 = time.perf_counter()
-            for k in range(n):
-                c = cs[k % len(cs)]
-                if k >= len(cs):
-                    c.sync()
-                c.zero_tally(); c.launch(args.photons, seed=900 + k, photon_offset=rank * args.photons, f32_walk=args.f32_walk)
-            for c in cs:
-                c.sync()
-            return (time.perf_counter() - t0) / n * 1e3
-        set_geometry(ctxs[0], 1)
-        run_jobs(ctxs[:1], 1)
-        t_one = run_jobs(ctxs[:1], 2)
-        set_geometry(ctxs[0], 2)
-        run_jobs(ctxs, 2)
-        t_two = run_jobs(ctxs, 4)
-        use_two = t_two < 0.97 * t_one
-        if distributed:     # every rank must take the same path: the collectives are issued per context in turn
-            flag = torch.tensor([1 if use_two else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            use_two = bool(flag.item())
-        probe = {"one_at_a_time_ms": t_one, "two_in_flight_ms": t_two, "chosen": 2 if use_two else 1}
-        if not use_two:
-            ctxs.pop().close()
-            depth = 1
-            set_geometry(ctxs[0], 1)
-    bpc = walk_bpc(depth)
-    info = ctxs[0].device_info()
-    per_gpu = args.photons
     offset = rank * per_gpu     # disjoint id ranges; streams depend on (seed, id) only
+
+    # ---- contexts: A serves one_call / one_at_a_time, A + B serve two_jobs
+    def new_ctx():
+        c = make_ctx()
+        configure(c, wl, args.tally)
+        c.set_tally_mode(args.tally_mode)
+        return c
+
+    ctx_a, ctx_b = new_ctx(), None
+    REGIMES = {"one_call": (1, 2), "two_jobs": (2, 1), "one_at_a_time": (1, 1)}   # name -> (contexts, lanes per launch)
+
+    def apply_regime(name):
+        nonlocal ctx_b
+        depth, lanes = REGIMES[name]
+        if depth == 2 and ctx_b is None:
+            ctx_b = new_ctx()
+        cs = [ctx_a, ctx_b][:depth]
+        for c in cs:
+            c.set_overlap(lanes)
+            # two jobs in flight: each job's walk takes half of the resident workgroups (f64: 2 of 4 per CU; f32: 3 of 5)
+            c.set_launch_config(((3 if args.f32_walk else 2) if depth == 2 else 0), 256 if depth == 2 else 0)
+            if args.tally_mode != "atomic":
+                c.reserve_log(per_gpu)    # scratch allocation is set-up, not part of a step (matters when --warmup 0)
+        return cs
+
+    def run_jobs(cs, n, seed0):
+        """n jobs over the contexts cs in turn, no collectives, host-timed: ms per job."""
+        for c in cs:
+            c.sync()
+        t0 = time.perf_counter()
+        for k in range(n):
+            c = cs[k % len(cs)]
+            if k >= len(cs):
+                c.sync()
+            c.zero_tally(); c.launch(per_gpu, seed=seed0 + k, photon_offset=offset, f32_walk=args.f32_walk)
+        for c in cs:
+            c.sync()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    probe = None
+    if args.inflight == 2:
+        regime = "two_jobs"
+    elif args.inflight == 1:
+        regime = "one_at_a_time" if args.overlap == 1 else "one_call"
+    elif args.tally_mode == "atomic":
+        regime = "one_at_a_time"
+    else:
+        # Untimed probe: which regime keeps THIS device busiest?  (Two streams only overlap when the runtime gives them
+        # separate hardware queues -- see GPU_MAX_HW_QUEUES above -- so it is measured, not assumed.)
+        probe = {}
+        for name in ("one_at_a_time", "one_call", "two_jobs"):
+            cs = apply_regime(name)
+            run_jobs(cs, len(cs), 900)                    # sizes the logs, pilot batch of a new scene
+            probe[name + "_ms"] = run_jobs(cs, 2 * len(cs), 910)
+        if distributed:     # every rank must take the same path: the collectives are issued per context in turn
+            for k in sorted(probe):
+                t = dev.scalar(probe[k], torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                probe[k] = float(t.item())
+        regime = min(REGIMES, key=lambda r: probe[r + "_ms"])
+        probe["chosen"] = regime
+    ctxs = apply_regime(regime)
+    depth, lanes = REGIMES[regime]
+    if depth == 1 and ctx_b is not None:
+        ctx_b.close(); ctx_b = None
+    info = ctxs[0].device_info()
 
     def barrier():
         for c in ctxs:
             c.sync()
-        torch.cuda.synchronize()
+        dev.sync()
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev.sync()
 
     kernel_ms, steps_per_launch, stages = [], [], []
 
@@ -210,15 +298,15 @@ def main():
         c.launch(per_gpu, seed=seed, photon_offset=offset, f32_walk=args.f32_walk)
 
     def finish(c, record):
-        """Complete the job in flight on c: wait, reduce over ranks (N > 1), read the 96-byte counters."""
+        """Complete the job in flight on c: reduce over ranks (N > 1; enqueued on the ctx stream), wait, read the
+        96-byte counters."""
         if distributed:
-            ltd.reduce_device(c, dst=0)       # RCCL sum of grid + counters to rank 0
-        else:
-            c.sync()
+            reduce_ctx(c)
+        c.sync()
         if record:
             kernel_ms.append(c.last_kernel_ms())
             st = c.last_log_stages()
-            if st is not None and st["batches"] == 1:
+            if st is not None:
                 stages.append(st)
             steps_per_launch.append(c.read_counters()["steps"])   # rank 0: the reduced sum; part of "tally readback"
 
@@ -239,101 +327,128 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = dev.scalar(elapsed, torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        km = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
+        km = dev.scalar(float(np.mean(kernel_ms)), torch.float64)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
         kernel_avg_ms = float(km.item())
     else:
         kernel_avg_ms = float(np.mean(kernel_ms))
 
-    # one job alone on the device, default launch geometry, outside the timed region: the latency of a single job
-    # and kernel durations that no other job overlaps (context for the per-kernel figures above)
-    alone = None
-    if rank == 0 and depth > 1 and not args.no_alone:
+    # After the timed region, rank 0: one job ALONE on the device in the one_at_a_time regime (kernel durations nothing
+    # overlaps: the per-kernel roofline figures) and the D2H readback of the grid into pinned host memory.
+    alone, readback_ms = None, None
+    if rank == 0 and not args.no_alone:
         c = ctxs[0]
-        set_geometry(c, 1)
-        ms = []
+        c.set_overlap(1); c.set_launch_config(0, 0)
+        ms, st = [], None
         for k in range(3):
             c.zero_tally(); c.launch(per_gpu, seed=500 + k, photon_offset=offset, f32_walk=args.f32_walk); c.sync()
             ms.append(c.last_kernel_ms())
-        st = c.last_log_stages()
+            st = c.last_log_stages()
         alone = {"job_ms": float(np.mean(ms[1:]))}
         if st is not None:
-            alone.update({k: st[k] for k in ("walk_ms", "partition_ms", "reduce_ms")})
+            alone.update({k: st[k] for k in ("walk_ms", "scan_ms", "partition_ms", "reduce_ms")})
+            alone["batches"] = st["batches"]
+        nbytes = wl["grid"] ** 3 * REC_VALUE_BYTES[args.tally]
+        buf = dev.host_buffer(nbytes)
+        rb = []
+        for k in range(3):
+            c.sync(); t1 = time.perf_counter(); c.read_grid_into(buf); rb.append((time.perf_counter() - t1) * 1e3)
+        readback_ms = float(min(rb[1:]))
 
     if rank == 0:
         total_steps = int(np.sum(steps_per_launch))          # reduced over ranks when distributed
         value = total_steps / elapsed
         steps_one_launch = total_steps / args.steps / world  # per rank per launch
         ms_per_step = elapsed / args.steps * 1e3
-        # With D jobs in flight a launch's own event-to-event time spans the other job's kernels too; the device
-        # completes one launch every ms_per_step, and that is the duration the algorithmic bytes are divided by.
-        # job_event_ms keeps the raw per-launch event time (what rocprofv3's kernel trace adds up to).
-        launch_ms = ms_per_step if depth > 1 else kernel_avg_ms
-        achieved = steps_one_launch * BYTES_PER_STEP[args.tally] / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get("%s_%s_%s" % ("f32walk" if args.f32_walk else "f64walk", args.tally,
-                                                              args.tally_mode))
-            except Exception:
-                traffic = None
+        # With work of several launches / lanes in flight a launch's own event-to-event time spans other kernels too;
+        # the device completes one launch every ms_per_step, and that is the duration the algorithmic bytes are divided
+        # by.  job_event_ms keeps the raw per-launch event time.
+        launch_ms = kernel_avg_ms if regime == "one_at_a_time" else ms_per_step
+        algo = steps_one_launch * BYTES_PER_STEP[args.tally]
+        achieved = algo / (launch_ms * 1e-3) / 1e9
+        sha = kernel_sources_sha()
+        key = "%s_%s_%s_%s" % (args.workload, "f32walk" if args.f32_walk else "f64walk", args.tally, args.tally_mode)
+        traffic, tsrc = None, {"file": "profiles/traffic.json", "key": key, "kernels_sha_now": sha}
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            ent = tj.get(key)
+            if ent:
+                tsrc.update({k: ent.get(k) for k in ("tag", "head", "kernels_sha", "photons")})
+                if ent.get("kernels_sha") == sha and ent.get("photons") == per_gpu:
+                    traffic = ent["bytes"]
+                else:
+                    tsrc["stale"] = "PMC pass taken on other kernel sources / another size: not reported as this run's traffic"
+        except Exception as e:      # no file: traffic stays null
+            tsrc["error"] = str(e)[:80]
         out = {
             "metric": "photon_steps_per_sec", "value": value, "unit": "photon-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.f32_walk else "f64", "data": "synthetic",
             "photons_per_sec": world * per_gpu * args.steps / elapsed,
-            "config": {"workload": "C2: %.0e photons per GPU, homogeneous semi-infinite slab (mu_a=0.1, mu_s=10, g=0.9, "
-                                   "n=1), %d^3 voxel grid (%.1f mm), pencil beam" % (per_gpu, GRID_N, VOXEL),
+            "config": {"workload": wl["text"] % (per_gpu, wl["grid"], wl["voxel"]),
                        "tally": args.tally, "tally_mode": args.tally_mode, "rng": "rocRAND XORWOW, re-seeded per photon",
-                       "jobs_in_flight": depth, "walk_workgroups_per_cu": bpc or "occupancy", "inflight_probe": probe,
-                       "parallelism": "photon-id sharding x%d, RCCL reduce of the grid to rank 0 per step" % world
-                       if world > 1 else "single GPU", "device": info["name"], "cus": info["cus"],
-                       "clock_mhz": info["clock_mhz"], "hbm_gib": round(info["hbm_bytes"] / 2 ** 30, 1)},
+                       "regime": regime, "jobs_in_flight": depth, "lanes_per_launch": lanes, "regime_probe": probe,
+                       "parallelism": "photon-id sharding x%d, RCCL reduce of the grid to rank 0 per step, enqueued on the "
+                                      "job's stream" % world if world > 1 else "single GPU",
+                       "device": info["name"], "cus": info["cus"], "clock_mhz": info["clock_mhz"],
+                       "hbm_gib": round(info["hbm_bytes"] / 2 ** 30, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                         "measured_gbs": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
                          "kernel": "walk_kernel + k_log_scan/part/reduce (one job)" if args.tally_mode == "log"
                          else "walk_kernel", "kernel_ms": launch_ms, "job_event_ms": kernel_avg_ms,
-                         "algorithmic_bytes_per_launch": steps_one_launch * BYTES_PER_STEP[args.tally]},
+                         "algorithmic_bytes_per_launch": algo},
         }
         if stages:
-            # per-kernel figures of the job, live from HIP events on each ctx's stream over the timed region
             rec = float(np.mean([x["records"] for x in stages]))
-            rb = 4 + {"f32": 4, "f64": 8, "u64fx": 8}[args.tally]          # bytes per deposit record in the log
-            pb = 2 * rb - 2                                                    # partition: read rb, write rb - 2
-            w, p_, r_ = (float(np.mean([x[k] for x in stages])) for k in ("walk_ms", "partition_ms", "reduce_ms"))
-            shared = " (shares the device with the other job in flight: durations overlap)" if depth > 1 else ""
-            out["roofline"]["kernels"] = [
-                {"kernel": "walk_kernel", "ms": w, "bound": "valu",
-                 "note": "349 VALU instr per photon-step (PMC SQ_INSTS_VALU, profiles/r01e_pmc_sq.csv); writes the %.1f GB deposit log%s"
-                         % (rec * rb / 1e9, shared),
-                 "photon_steps_per_sec": steps_one_launch / (w * 1e-3)},
-                {"kernel": "k_log_part", "ms": p_, "bound": "hbm", "achieved": pb * rec / (p_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "frac": pb * rec / (p_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "note": "algorithmic: every record read once (%d B) and written once (%d B: 2-byte in-tile position)" % (rb, rb - 2) + shared},
-                {"kernel": "k_log_reduce", "ms": r_, "bound": "hbm", "achieved": (rb - 2) * rec / (r_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "frac": (rb - 2) * rec / (r_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "note": "algorithmic: every record read once (%d B)" % (rb - 2) + shared}]
+            rb_ = 4 + REC_VALUE_BYTES[args.tally]                              # bytes per deposit record in the log
+            passes = 2 if wl["grid"] ** 3 > 1024 * 16384 else 1
+            part_bytes = rec * ((2 * rb_ - 2) if passes == 1 else (2 * rb_ + 4 + 2 * rb_ - 2))   # + pass 2 and the tile count's index read
             out["roofline"]["deposit_records_per_launch"] = rec
+            out["roofline"]["kernels_overlapped_ms"] = {
+                k: float(np.mean([x[k] for x in stages])) for k in ("walk_ms", "partition_ms", "reduce_ms")}
+            out["roofline"]["kernels_overlapped_ms"]["note"] = (
+                "sums of the kernels' own event-to-event times over the timed region; with several jobs / lanes in "
+                "flight these overlap in time and are NOT per-step kernel times")
+            if alone and "walk_ms" in alone:
+                w, p_, r_ = alone["walk_ms"], alone["partition_ms"], alone["reduce_ms"]
+                out["roofline"]["kernels"] = [
+                    {"kernel": "walk_kernel", "ms": w, "bound": "valu", "regime": "one job alone",
+                     "note": "~350 VALU instr per photon-step (PMC SQ_INSTS_VALU); writes the %.1f GB deposit log" % (rec * rb_ / 1e9),
+                     "photon_steps_per_sec": steps_one_launch / (w * 1e-3)},
+                    {"kernel": "k_log_part (+ k_log_count2)" if passes == 2 else "k_log_part", "ms": p_, "bound": "hbm",
+                     "regime": "one job alone", "achieved": part_bytes / (p_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": part_bytes / (p_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "note": "algorithmic: %s" % ("every record read once (%d B) and written once (%d B: 2-byte in-tile position)" % (rb_, rb_ - 2)
+                                                  if passes == 1 else
+                                                  "two passes: %d B read + %d B written, 4 B index re-read for the tile count, %d B read + %d B written" % (rb_, rb_, rb_, rb_ - 2))},
+                    {"kernel": "k_log_reduce", "ms": r_, "bound": "hbm", "regime": "one job alone",
+                     "achieved": (rb_ - 2) * rec / (r_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (rb_ - 2) * rec / (r_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "note": "algorithmic: every record read once (%d B)" % (rb_ - 2)}]
         if alone:
-            alone["note"] = ("one job alone on the device (default launch geometry, 4 waves/SIMD), 2 launches after the timed "
-                             "region: single-job latency and kernel durations nothing overlaps")
-            if "partition_ms" in alone and stages:
-                alone["k_log_part_frac"] = pb * rec / (alone["partition_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-                alone["k_log_reduce_frac"] = (rb - 2) * rec / (alone["reduce_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            alone["note"] = ("one job alone on the device, one lane (default launch geometry, 4 waves/SIMD), 2 launches after the "
+                             "timed region: single-job latency and kernel durations nothing overlaps")
             out["roofline"]["one_job_alone"] = alone
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+        if readback_ms is not None:
+            gb = wl["grid"] ** 3 * REC_VALUE_BYTES[args.tally] / 1e9
+            out["readback"] = {"ms": readback_ms, "bytes": gb * 1e9, "gbs": gb / (readback_ms * 1e-3),
+                               "note": "D2H of the raw grid into pinned host memory (one rank), outside the timed region",
+                               "photon_steps_per_sec_incl_readback": steps_one_launch / ((launch_ms + readback_ms) * 1e-3),
+                               "photons_per_sec_incl_readback": per_gpu / ((launch_ms + readback_ms) * 1e-3)}
+        if not args.no_cpu_baseline and world == 1 and not fake:
+            out["cpu_baseline"] = cpu_baseline(wl, args.workload)
         print(json.dumps(out))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
-    for c in ctxs:
-        c.close()
+    for c in [ctx_a, ctx_b]:
+        if c is not None:
+            c.close()
 
 
 if __name__ == "__main__":

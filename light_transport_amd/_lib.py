@@ -282,6 +282,13 @@ class Context:
         self._ck(lib().lt_read_grid(self._h, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)), "lt_read_grid")
         return out
 
+    def read_grid_into(self, buf):
+        """Raw tally into a caller-owned contiguous buffer of exactly the grid's size in bytes (e.g. pinned host
+        memory: the D2H copy then runs at the link's rate)."""
+        a = np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
+        self._ck(lib().lt_read_grid(self._h, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes)), "lt_read_grid")
+        return buf
+
     def read_grid(self):
         """Absorbed weight per voxel as float64 [nz, ny, nx]."""
         out = np.empty(self._grid_shape, dtype=np.float64)

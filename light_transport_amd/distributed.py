@@ -45,18 +45,28 @@ def device_counter_tensors(ctx):
     return ints, flts
 
 
-def reduce_device(ctx, group=None, dst=None):
-    """Sum-reduce grid and counters in place in HBM with torch.distributed
-    (backend "nccl" == RCCL on ROCm).  dst=None: all-reduce."""
-    ctx.sync()  # the walk ran on the ctx stream; the collective runs on torch's
+def reduce_device(ctx, group=None, dst=None, wait=False):
+    """Sum-reduce grid and counters in place in HBM with torch.distributed (backend "nccl" == RCCL on ROCm),
+    dst=None: all-reduce.  The collectives are issued with the ctx's own HIP stream as torch's current stream, so
+    they are ordered behind the launch that produced the grid and in front of whatever the caller enqueues on the
+    ctx next (counters readback, the next zero_tally) WITHOUT the host waiting for either: torch's NCCL process
+    group makes its communication stream wait for the current stream's work and, at ``Work.wait()``, the current
+    stream for the communication -- both are stream-level events.  Other contexts of the process keep running
+    meanwhile (two jobs in flight: one job's reduce travels over xGMI while the other job walks).
+    wait=True additionally blocks the host until this ctx's stream has drained."""
+    stream = torch.cuda.ExternalStream(ctx.stream(), device=torch.device("cuda", ctx.device_id))
     tensors = (device_grid_tensor(ctx),) + device_counter_tensors(ctx)
-    for t in tensors:
-        if dst is None:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        else:
-            dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    # wait for the collective only (torch's stream), not for other contexts' streams that may have jobs in flight
-    torch.cuda.current_stream(ctx.device_id).synchronize()
+    with torch.cuda.stream(stream):
+        works = []
+        for t in tensors:
+            if dst is None:
+                works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True))
+            else:
+                works.append(dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        for w in works:
+            w.wait()          # stream-level for the NCCL backend: the ctx stream waits, the host does not
+    if wait:
+        ctx.sync()
 
 
 def reduce_host(grid, counters, group=None, dst=None):

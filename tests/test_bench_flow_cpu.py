@@ -1,0 +1,74 @@
+"""CPU suite: bench.py's N > 1 control flow at world size 2 over gloo with recording stand-in contexts
+(tests/fake_ctx.py) -- the probe's rank agreement, the launch / reduce / readback order per regime, the JSON line.
+The first 8-GPU run of the real thing must not be the first time this host logic executes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(tmp_path, extra, nproc=2):
+    log = os.path.join(str(tmp_path), "calls")
+    env = dict(os.environ, LT_FAKE_LOG=log, PYTHONPATH=ROOT)
+    port = 29700 + (os.getpid() % 1500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--backend", "gloo",
+           "--ctx-factory", "tests.fake_ctx:make", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line, from rank 0: %r" % lines
+    calls = [[json.loads(l) for l in open("%s.%d.jsonl" % (log, rk))] for rk in range(nproc)]
+    return json.loads(lines[0]), calls
+
+
+@pytest.mark.parametrize("regime,flags", [("two_jobs", ["--inflight", "2"]), ("one_call", ["--inflight", "1"]),
+                                          ("one_at_a_time", ["--inflight", "1", "--overlap", "1"]), ("probe", [])])
+def test_bench_control_flow_world_size_2(tmp_path, regime, flags):
+    K, W, n = 5, 2, 1000
+    out, calls = run_bench(tmp_path, flags + ["--steps", str(K), "--warmup", str(W), "--photons", str(n)])
+    assert out["metric"] == "photon_steps_per_sec" and out["n_gpus"] == 2 and out["steps"] == K and out["warmup"] == W
+    assert out["scaling"] == "weak" and out["higher_is_better"] is True and out["vs_baseline"] is None
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "measured_gbs"}
+    chosen = out["config"]["regime"]
+    if regime == "probe":
+        assert out["config"]["regime_probe"]["chosen"] == chosen
+        assert {"one_call_ms", "two_jobs_ms", "one_at_a_time_ms"} <= set(out["config"]["regime_probe"])
+    else:
+        assert chosen == regime and out["config"]["regime_probe"] is None
+    # value = photon-steps of ALL ranks (reduced to rank 0) / wall: the fake job reports 281 * n + seed steps per rank
+    timed_seeds = range(K)
+    expect_steps = sum(2 * (281 * n + s) for s in timed_seeds)
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * K - expect_steps) < 1e-6 * expect_steps
+    for rk, cl in enumerate(calls):
+        # both ranks issue the same sequence of operations per context (collectives in the same order)
+        def sig(x):      # (rank 0 alone runs three more jobs, seeds 500.., after the timed region)
+            return [(c["ctx"], c["op"]) for c in x if c["op"] == "reduce" or (c["op"] == "launch" and not 500 <= c["seed"] < 503)]
+        assert sig(cl) == sig(calls[0])
+        launches = [c for c in cl if c["op"] == "launch" and not 500 <= c["seed"] < 503]
+        assert all(c["offset"] == rk * n and c["n"] == n for c in launches)          # disjoint photon-id ranges
+        timed = [c for c in launches if c["seed"] < K]
+        assert sorted(c["seed"] for c in timed) == list(timed_seeds)                   # EXACTLY K timed steps
+        assert len([c for c in launches if 1000 <= c["seed"] < 1000 + W]) == W       # W warm-up steps
+        reduces = [c for c in cl if c["op"] == "reduce"]
+        assert len(reduces) == K + W                                                   # one reduce per job, none in the probe
+        # on every context: zero_tally -> launch -> reduce -> (sync) before the next launch
+        state = {}
+        for c in cl:
+            if c["op"] == "launch":
+                assert state.get(c["ctx"]) in (None, "idle", "zeroed"), (rk, c)
+                state[c["ctx"]] = "flying"
+            elif c["op"] == "reduce":
+                assert state.get(c["ctx"]) == "flying"
+            elif c["op"] == "sync":
+                state[c["ctx"]] = "idle"
+    depth = {"two_jobs": 2, "one_call": 1, "one_at_a_time": 1}[chosen]
+    assert out["config"]["jobs_in_flight"] == depth
+    timed_ctx = {c["ctx"] for c in calls[0] if c["op"] == "launch" and c["seed"] < K}
+    assert len(timed_ctx) == depth
+    # only rank 0 reads the grid back, after the timed region
+    assert any(c["op"] == "read_grid_into" for c in calls[0]) and not any(c["op"] == "read_grid_into" for c in calls[1])
