@@ -442,12 +442,17 @@ template <typename R> LT_DEV void spin(R* u, R ct, R xi_phi)
 // ---------------------------------------------------------------------------
 // RNG: rocRAND XORWOW, one stream per photon
 // ---------------------------------------------------------------------------
-LT_DEV unsigned long long mix_seed(unsigned long long seed, unsigned long long photon_id)
-{   // splitmix64 finaliser over (seed, photon id)
-    unsigned long long z = seed + (photon_id + 1ull) * 0x9E3779B97F4A7C15ull;
+LT_DEV unsigned long long mix64(unsigned long long z)
+{   // splitmix64's output function
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
+}
+// One stream per (seed, photon id), hashed in two stages -- the seed first, then the id into the hashed seed -- so that
+// no pair (seed + k c, id - k) shares a stream with (seed, id), as a single hash of seed + (id + 1) c would.
+LT_DEV unsigned long long mix_seed(unsigned long long seed, unsigned long long photon_id)
+{
+    return mix64(mix64(seed + 0x9E3779B97F4A7C15ull) ^ ((photon_id + 1ull) * 0x9E3779B97F4A7C15ull));
 }
 
 // One stream per photon.  rocrand_init from a seed alone leaves three of the five XORWOW state words offset by the

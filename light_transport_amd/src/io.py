@@ -47,7 +47,17 @@ def triangles_from_mesh(vertices, faces, material, scale=1.0, translate=(0.0, 0.
     return out
 
 
-def load_obj(path, material, scale=1.0, translate=(0.0, 0.0, 0.0)):
-    """Reference call shape ``load_obj(path, ...)`` -> list of primitives."""
-    v, f = read_obj(path)
-    return triangles_from_mesh(v, f, material, scale, translate)
+def load_obj(file_path, material=None, scale=1.0, translate=(0.0, 0.0, 0.0)):
+    """Reference call shape (src/io.py:11-40): ``objects, dimension = load_obj(file_path)``.  ``objects`` are
+    ``PreComputedTriangle`` primitives (the reference built legacy ``Triangle`` objects with a stale ``Material(...)``
+    call; the BVH builder and the kernels consume PreComputedTriangle), ``dimension`` = abs(max(xmax, ymax, zmax)) of
+    the file's vertices as the reference computes it (:24-27, before any scale / translate).  ``material`` defaults
+    to the reference's choice, a red material with shininess 100 and reflection 0.5 (:33); scale / translate are
+    extensions."""
+    from .constants import RED
+    from .material import Material
+    if material is None:
+        material = Material(color=RED, shininess=100, reflection=0.5, ior=1.0)
+    v, f = read_obj(file_path)
+    dimension = abs(float(v.max(axis=0).max())) if len(v) else 0.0
+    return triangles_from_mesh(v, f, material, scale, translate), dimension

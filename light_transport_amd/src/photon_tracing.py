@@ -94,6 +94,9 @@ def uniform_table(n_photons, steps, seed=0):
     return np.random.RandomState(seed).rand(int(n_photons), int(steps), 4)
 
 
+DEFAULT_MAX_STEPS = 1000000      # lt.h: the walk's hard cap
+
+
 class PhotonTracer:
     """Owns one device context; ``configure`` once, ``run`` as often as needed
     (runs accumulate until ``reset``)."""
@@ -127,8 +130,13 @@ class PhotonTracer:
                            list(source.edge_1) + list(source.edge_2), start_medium)
         else:
             raise TypeError("source must be a PencilBeam or an AreaLight")
-        if max_steps is not None:
-            ctx.set_max_steps(max_steps)
+        # every per-call setting is (re)set here, so that a call's result never depends on what an earlier user of the
+        # same context left behind (the function-style API shares one context per device)
+        ctx.set_max_steps(DEFAULT_MAX_STEPS if max_steps is None else max_steps)
+        ctx.set_tally_mode("auto", 0)
+        ctx.set_overlap(0)
+        ctx.set_launch_config(0, 0)
+        ctx.set_vertex_capture(0)
         self.grid = grid
         return self
 

@@ -21,12 +21,16 @@
  * restatement bit-for-bit against the device generator (lt_rng_raw). -------- */
 typedef struct lto_xorwow { uint32_t x[5]; uint32_t d; } lto_xorwow;
 
-static inline uint64_t lto_mix_seed(uint64_t seed, uint64_t photon_id)
-{   /* splitmix64 finaliser over (seed, photon id): one stream per photon */
-    uint64_t z = seed + (photon_id + 1) * 0x9E3779B97F4A7C15ULL;
+static inline uint64_t lto_mix64(uint64_t z)
+{   /* splitmix64's output function */
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
+}
+static inline uint64_t lto_mix_seed(uint64_t seed, uint64_t photon_id)
+{   /* one stream per (seed, photon id), hashed in two stages: the seed first, then the id into the hashed seed -- so
+     * that no pair (seed + k*c, id - k) shares a stream with (seed, id), as a single hash of seed + (id + 1)*c would */
+    return lto_mix64(lto_mix64(seed + 0x9E3779B97F4A7C15ULL) ^ ((photon_id + 1) * 0x9E3779B97F4A7C15ULL));
 }
 
 static inline void lto_xorwow_seed(lto_xorwow* s, uint64_t seed)

@@ -97,8 +97,11 @@ def h4(v, w):
 def main():
     R = import_reference()
     sys.path.insert(0, REPO)
-    if sys.argv[1:] == ["g9"]:          # only the newest fixture; the others are unchanged by it
+    if sys.argv[1:] == ["g9"]:          # only one fixture; the others are unchanged by it
         g9_render_old(R)
+        return
+    if sys.argv[1:] == ["g10"]:
+        g10_obj_meshes(R)
         return
     rs = np.random.RandomState(20240925)
     mat = R["material"].Material(R["material"].Color(np.zeros(3), np.ones(3), np.ones(3)), 1.0, 0.1, 1.5)
@@ -216,7 +219,74 @@ def main():
              rand_1=sc.rand_1, image_shape=np.array(sc.image.shape))
     g8_render(R)
     g9_render_old(R)
+    g10_obj_meshes(R)
     print("golden vectors written to", OUT)
+
+
+def _g10_chunk(args):
+    """Brute-force nearest hit of a chunk of rays over all triangles with the reference's triangle_intersect and its
+    predicate EPSILON < t < min_distance (bvh_new.py:438); runs in a forked worker (the reference is already imported)."""
+    tri_fn, eps, ref_tris, org, dirs = args
+    prim = -np.ones(len(org), dtype=np.int32); tt = np.full(len(org), np.inf); second = np.full(len(org), np.inf)
+    for i in range(len(org)):
+        o4, d4 = h4(org[i], 1), h4(dirs[i], 0)
+        best = np.inf
+        for j, tri in enumerate(ref_tris):
+            t = tri_fn(o4, d4, tri)
+            if t is not None and eps < t:
+                if t < best:
+                    second[i] = best; best, prim[i] = t, j
+                elif t < second[i]:
+                    second[i] = t
+        if prim[i] >= 0:
+            tt[i] = best
+    return prim, tt, second
+
+
+def g10_obj_meshes(R):
+    """G10: the reference's on-disk input.  Vertices and faces of examples/obj/{teapot,cow,pumpkin}.obj
+    (6320 / 5804 / 10000 triangles: the meshes beyond the LDS budget), parsed HERE by a minimal reader of its own, and
+    the brute-force nearest hit of 600 rays per mesh computed with the reference's triangle_intersect on
+    PreComputedTriangles built by the reference's own constructor.  `second` = the second-nearest t (ties / shared
+    edges can be told apart in the tests).  Numbers only."""
+    import multiprocessing as mp
+    obj_dir = os.path.join(REF, "LightTransportSimulator", "light_transport", "examples", "obj")
+    mat = R["material"].Material(R["material"].Color(np.zeros(3), np.ones(3), np.ones(3)), 1.0, 0.1, 1.5)
+    PCT = R["primitives"].PreComputedTriangle
+    tri_fn, eps = R["intersects"].triangle_intersect, R["constants"].EPSILON
+    out = {}
+    rs = np.random.RandomState(1010)
+    for name in ("teapot", "cow", "pumpkin"):
+        verts, faces = [], []
+        for line in open(os.path.join(obj_dir, name + ".obj"), errors="replace"):
+            p = line.split()
+            if not p:
+                continue
+            if p[0] == "v":
+                verts.append([float(x) for x in p[1:4]])
+            elif p[0] == "f":
+                idx = [int(tok.split("/")[0]) for tok in p[1:]]
+                idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                faces += [[idx[0], idx[k], idx[k + 1]] for k in range(1, len(idx) - 1)]
+        v, f = np.array(verts, dtype=np.float64), np.array(faces, dtype=np.int32)
+        nz = np.array([np.dot(n, n) > 0 for n in np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])])
+        f = f[nz]                                             # zero-area faces have no normal: PreComputedTriangle would hold NaNs
+        ref_tris = [PCT(h4(v[a], 1), h4(v[b], 1), h4(v[c], 1), mat) for a, b, c in f]
+        lo, hi = v.min(axis=0), v.max(axis=0)
+        ext = hi - lo
+        nr = 600
+        org = lo - 0.3 * ext + rs.rand(nr, 3) * 1.6 * ext     # inside and around the bounding box
+        tgt = lo + rs.rand(nr, 3) * ext
+        dirs = tgt - org; dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        chunks = np.array_split(np.arange(nr), 16)
+        with mp.get_context("fork").Pool(8) as pool:
+            res = pool.map(_g10_chunk, [(tri_fn, eps, ref_tris, org[c], dirs[c]) for c in chunks])
+        out[name + "_verts"] = v; out[name + "_faces"] = f
+        out[name + "_origins"] = org; out[name + "_dirs"] = dirs
+        out[name + "_prim"] = np.concatenate([r[0] for r in res]); out[name + "_t"] = np.concatenate([r[1] for r in res])
+        out[name + "_second"] = np.concatenate([r[2] for r in res])
+        print(name, len(v), "vertices", len(f), "triangles", int((out[name + "_prim"] >= 0).sum()), "of", nr, "rays hit", flush=True)
+    np.savez_compressed(os.path.join(OUT, "g10_obj_meshes.npz"), **out)
 
 
 def g8_render(R):

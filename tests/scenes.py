@@ -167,3 +167,49 @@ def check_g9_image(img, rand_0_after, g9, name):
     marks = np.isinf(g9[name + "_rand_0_after"])
     assert np.array_equal(np.isinf(rand_0_after), marks) and marks.sum() > 100
     assert g9[name + "_shadow_rays"].max() > 4 and img.sum() > 10   # the recursion really branched
+
+
+def obj_in_box(verts, faces, n=40, split_method=0, half=4.0, **kw):
+    """f3 scene: a mesh that came through the OBJ loader (G10: teapot / cow / pumpkin of the reference's assets),
+    scaled to fit and centred in a closed box, SAH-built; an absorbing medium on the back side of its triangles.
+    Returns (problem, ordered triangles, linear BVH, index of every ordered mesh triangle in `faces` or -1 for walls)."""
+    from light_transport_amd.src.io import triangles_from_mesh
+    v = np.asarray(verts, dtype=np.float64)
+    lo, hi = v.min(axis=0), v.max(axis=0)
+    scale = 0.6 * 2 * half / float((hi - lo).max())
+    shift = -0.5 * (lo + hi) * scale
+    walls = cb.get_cornell_box(half, K.GLASS_MAT, K.GLASS_MAT, K.GLASS_MAT) + cb.get_front_wall(half, K.GLASS_MAT) \
+        + cb.get_light_quad(half, K.GLASS_MAT)
+    for t in walls:
+        t.med_front, t.med_back, t.face_index = 0, -1, -1
+    body = triangles_from_mesh(v, faces, K.GLASS_MAT, scale, shift, drop_degenerate=False)
+    for k, t in enumerate(body):
+        t.med_front, t.med_back, t.face_index = 0, 1, k
+    ordered, linear = B.build_linear_bvh(walls + body, split_method)
+    mesh = dict(verts=B.triangles_array(ordered), med_front=np.array([t.med_front for t in ordered], np.int32),
+                med_back=np.array([t.med_back for t in ordered], np.int32), nodes=B.linear_bvh_arrays(linear))
+    media = [(0.05, 5.0, 0.8, 1.0), (0.8, 8.0, 0.9, 1.37)]
+    src = dict(type=1, pos=(-1.0, half, -1.0), dir=(0.0, -1.0, 0.0), extra=(2.0, 0.0, 0.0, 0.0, 0.0, 2.0), start_medium=0)
+    voxel = 2 * half / n
+    prob = Problem(media, (n, n, n), (-half, -half, -half), (voxel,) * 3, mesh=mesh, source=src, **kw)
+    return prob, ordered, linear, np.array([t.face_index for t in ordered]), scale, shift
+
+
+def share_an_edge(tri_a, tri_b, tol=1e-9):
+    """Two triangles ([3, 3] vertex arrays) with at least two common vertices."""
+    common = sum(1 for p in tri_a if np.any(np.all(np.abs(tri_b - p) <= tol * (1.0 + np.abs(p).max()), axis=1)))
+    return common >= 2
+
+
+def check_hits_against_fixture(prim, t, fix_prim, fix_t, fix_second, tris, rtol=1e-12):
+    """Nearest hits (triangle index into `tris`, distance) against a brute-force fixture.  Index and decision work is
+    exact: a differing triangle is accepted ONLY as a tie -- the same distance to rtol on two triangles that share an
+    edge (the ray passes through the common edge; which of the two claims it is decided in the last bit)."""
+    assert np.array_equal(prim >= 0, fix_prim >= 0), "hit / miss decisions differ"
+    hit = fix_prim >= 0
+    np.testing.assert_allclose(t[hit], fix_t[hit], rtol=rtol)
+    diff = np.flatnonzero(hit & (prim != fix_prim))
+    for i in diff:
+        assert abs(fix_second[i] - fix_t[i]) <= 1e-9 * fix_t[i], "ray %d: another triangle although the hit is not a tie" % i
+        assert share_an_edge(tris[prim[i]], tris[fix_prim[i]]), "ray %d: tie between triangles that share no edge" % i
+    return len(diff)

@@ -34,7 +34,8 @@ def test_extension_is_loaded_and_device_is_mi355x(ctx):
 
 
 def test_xorwow_matches_rocrand_device_generator(ctx):
-    for seed, pid in ((0, 0), (42, 1), (2 ** 63 + 5, 10 ** 12 + 7), (7, 2 ** 40)):
+    c = 0x9E3779B97F4A7C15       # (seed + k c, id - k): the pairs a single-stage hash would have aliased
+    for seed, pid in ((0, 0), (42, 1), (2 ** 63 + 5, 10 ** 12 + 7), (7, 2 ** 40), (5, 10), ((5 + c) % 2 ** 64, 9)):
         np.testing.assert_array_equal(ctx.rng_raw(seed, pid, 257), O.rng_raw(seed, pid, 257))
 
 
@@ -60,9 +61,10 @@ def test_g3_intersect_bounds(ctx, golden_dir):
     g3 = load(golden_dir, "g3_intersect_bounds.npz")
     boxes = np.concatenate([g3["lo"], g3["hi"]], axis=1)
     hit = ctx.intersect_bounds(g3["origins"], g3["dirs"], boxes, g3["tmax"])
+    # decisions are exact: the slab test is (bound - origin) * inv_dir, compares and one widening product --
+    # nothing a fused multiply-add could change
     bad = np.flatnonzero(hit != g3["hit"])
-    # a fused multiply-add may move t_near/t_far by one ulp: only exact-tie rays may differ
-    assert len(bad) <= 3, "intersect_bounds differs from the reference on %d rays" % len(bad)
+    assert len(bad) == 0, "intersect_bounds differs from the reference on rays %s" % bad[:10]
 
 
 def test_g4_nearest_hit(ctx, golden_dir):
@@ -364,6 +366,13 @@ def test_trace_photons_one_call_api(ctx):
     assert dose.shape == (64, 64, 64) and dose.dtype == np.float64
     S.assert_grid_close(dose, go)
     assert cnt["steps"] == co["steps"]
+    # a call is a pure function of its arguments: settings of an earlier call on the shared context do not leak
+    capped = PT.trace_photons(slab, None, None, 2000, seed=0, grid=grid, source=PT.PencilBeam((0, 0, 0), (0, 0, 1)), max_steps=5,
+                              return_counters=True)[1]
+    again = PT.trace_photons(slab, None, None, 2000, seed=0, grid=grid, source=PT.PencilBeam((0, 0, 0), (0, 0, 1)),
+                             return_counters=True)[1]
+    assert capped["w_capped"] > 1000 and capped["steps"] <= 5 * 2000
+    assert again["w_capped"] == 0 and again["steps"] > 100 * 2000
     # mesh scene through the object API
     ordered, linear = S.cornell_scene()
     vol = PT.MeshVolume([PT.OpticalMedium(0.1, 10.0, 0.9, 1.0), PT.OpticalMedium(1.0, 5.0, 0.8, 1.5)], start_medium=0)
@@ -389,9 +398,15 @@ def test_large_mesh_in_global_memory(ctx):
     p0, t0 = B.intersect_bvh_batch(o, d, ordered, linear, tmax, False, ctx)
     np.testing.assert_array_equal(p1, p0); np.testing.assert_array_equal(t1, t0)
     po, to = prob.oracle().intersect_rays(o, d, tmax, use_bvh=True)
-    same = p1 == po
-    assert same.mean() > 0.9995        # a shared-edge hit may resolve to the neighbour triangle under FMA
-    np.testing.assert_allclose(t1[same], to[same], rtol=1e-11)
+    # index work is exact; a different triangle is only accepted as a tie: equal distance on two triangles that share
+    # an edge (which of them claims a ray through the common edge is decided in the last bit, and the kernel fuses
+    # multiply-adds where the oracle does not)
+    assert np.array_equal(p1 >= 0, po >= 0)
+    np.testing.assert_allclose(t1[p1 >= 0], to[p1 >= 0], rtol=1e-11)
+    verts3 = B.triangles_array(ordered).reshape(-1, 3, 3)
+    for i in np.flatnonzero(p1 != po):
+        assert S.share_an_edge(verts3[p1[i]], verts3[po[i]]), "ray %d: different triangles that share no edge" % i
+    assert (p1 != po).mean() < 2e-3
     assert (p1 >= 0).mean() > 0.5
     n = 20000
     prob.apply(ctx, "u64fx")
@@ -401,6 +416,52 @@ def test_large_mesh_in_global_memory(ctx):
     check_counters(c, co, n)
     assert int((fx != fxo).sum()) == 0
     assert c["w_escaped_mesh"] > 0 and fx.sum() > 0
+
+
+# ---------------------------------------------------------------- f3: meshes that came through the OBJ loader (G10)
+@pytest.mark.parametrize("name", ["teapot", "cow", "pumpkin"])
+def test_g10_obj_meshes_on_the_gpu(ctx, golden_dir, tmp_path, name):
+    """The reference's on-disk input (examples/obj/*.obj; S/io.py:11-40) on the device: fixture vertices / faces ->
+    OBJ file -> load_obj -> SAH build_bvh (S/bvh_new.py:198-258) -> traversal in global memory (the tables are far
+    beyond the LDS budget).  Nearest hits of the fixture's rays == the reference's triangle_intersect run over every
+    triangle (brute force); the fixed-point walk through the mesh == the CPU oracle bit for bit."""
+    g = load(golden_dir, "g10_obj_meshes.npz")
+    from light_transport_amd.src import bvh_new as B, constants as K
+    from light_transport_amd.src.io import load_obj
+    v, f = g[name + "_verts"], g[name + "_faces"]
+    path = tmp_path / (name + ".obj")            # the same forms the reference's assets use: v x y z / f a b c / f a//n b//n c//n
+    with open(path, "w") as fh:
+        fh.write("# %s (G10 fixture)\n" % name)
+        for p in v:
+            fh.write("v %r %r %r\n" % (float(p[0]), float(p[1]), float(p[2])))
+        for k, (a, b, c) in enumerate(f):
+            fh.write(("f %d//%d %d//%d %d//%d\n" % (a + 1, 1, b + 1, 1, c + 1, 1)) if k % 2 else ("f %d %d %d\n" % (a + 1, b + 1, c + 1)))
+    objects, dimension = load_obj(str(path), K.GLASS_MAT)
+    assert len(objects) == len(f) and dimension == abs(v.max())
+    for k, t in enumerate(objects):
+        t.face_index = k
+    ordered, linear = B.build_linear_bvh(objects, 0)
+    back = np.array([t.face_index for t in ordered])
+    tri_xyz = v[f]
+    for use_bvh in (True, False):
+        prim, t = B.intersect_bvh_batch(g[name + "_origins"], g[name + "_dirs"], ordered, linear, None, use_bvh, ctx)
+        got = np.where(prim >= 0, back[np.maximum(prim, 0)], -1)
+        ties = S.check_hits_against_fixture(got, t, g[name + "_prim"], g[name + "_t"], g[name + "_second"], tri_xyz)
+        assert ties <= 6
+    assert (g[name + "_prim"] >= 0).sum() > 300
+    # the walk through the loader's mesh, GEOM 2 (global-memory traversal), both tally paths
+    prob, ordered2, _, _, _, _ = S.obj_in_box(v, f)
+    assert len(ordered2) == len(f) + 20
+    n = 6000
+    _, fxo, co = prob.oracle().run(n, seed=61, threads=8, want_fx=True, want_f64=False)
+    for mode in ("atomic", "log"):
+        prob.apply(ctx, "u64fx"); ctx.set_tally_mode(mode)
+        ctx.launch(n, seed=61); ctx.sync()
+        c = ctx.read_counters()
+        check_counters(c, co, n)
+        assert np.array_equal(ctx.read_grid_raw(), fxo), mode
+    ctx.set_tally_mode("auto")
+    assert c["w_absorbed"] > 0.05 * n
 
 
 # ---------------------------------------------------------------- f2: surface path tracer vs the reference render

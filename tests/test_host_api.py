@@ -169,8 +169,10 @@ def test_obj_loader(tmp_path):
                  "f 1 2 3 4\nf 1//1 2//1 5//1\nf 1/1/1 3/1/1 5/1/1\nf -5 -4 -1\ns off\nusemtl x\n")
     v, f = read_obj(str(p))
     assert v.shape == (5, 3) and f.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 4], [0, 2, 4], [0, 1, 4]]
-    tris = load_obj(str(p), K.GLASS_MAT, scale=2.0, translate=(1, 0, 0))
+    tris, dim = load_obj(str(p), K.GLASS_MAT, scale=2.0, translate=(1, 0, 0))
     assert len(tris) == 5 and np.allclose(tris[0].vertex_2[:3], [3, 0, 0]) and tris[0].vertex_2[3] == 1.0
+    objects, dimension = load_obj(str(p))          # the reference's call shape: (objects, dimension), default material
+    assert len(objects) == 5 and dimension == float(v.max()) and objects[0].material.reflection == 0.5
     (tmp_path / "bad.obj").write_text("v 0 0 0\nf 1 2 3\n")
     with pytest.raises(ValueError):
         read_obj(str(tmp_path / "bad.obj"))

@@ -162,8 +162,13 @@ def test_xorwow_known_answer():
     assert np.array_equal(a, b)
     # the per-photon stream is DEFINED as: xorwow seeded with splitmix64(seed, id), first 8 outputs discarded
     # (why); pinned so that a change of that definition cannot slip in unnoticed
-    assert list(O.rng_raw(0, 0, 4)) == [1103228482, 1806729144, 594538611, 1790927445]
-    assert list(O.rng_raw(12345, 678, 4)) == [1926655411, 2439364131, 499062357, 4025134735]
+    assert list(O.rng_raw(0, 0, 4)) == [1518142444, 3133822812, 2944562092, 3742290185]
+    assert list(O.rng_raw(12345, 678, 4)) == [4012408452, 417106803, 2151336039, 3289225771]
+    # seed and id are hashed in two stages: (seed + k*c, id - k) must NOT alias (seed, id) (it did with one hash of
+    # seed + (id + 1)*c, c = 0x9E3779B97F4A7C15)
+    c = 0x9E3779B97F4A7C15
+    assert not np.array_equal(O.rng_raw(5, 10, 8), O.rng_raw((5 + c) % 2 ** 64, 9, 8))
+    assert not np.array_equal(O.rng_raw(5, 10, 8), O.rng_raw((5 + 3 * c) % 2 ** 64, 7, 8))
     assert len(set(O.rng_raw(0, i, 1)[0] for i in range(1000))) == 1000  # distinct streams per photon
     # statistical sanity of the uniforms
     v = np.concatenate([O.rng_raw(5, i, 256) for i in range(400)]).astype(np.float64) / 2 ** 32
@@ -273,3 +278,42 @@ def test_f32_oracle_tracks_f64_statistically():
     g32, _, c32 = prob.oracle().run(20000, seed=6, threads=4, walk_f32=True)
     assert abs(c64["w_absorbed"] - c32["w_absorbed"]) / 20000 < 0.01
     assert abs(O.conservation_residual(c32)) < 2e-6 * 20000
+
+
+# ---------------------------------------------------------------- G10: the reference's OBJ assets (f3)
+@pytest.mark.parametrize("name", ["teapot", "cow", "pumpkin"])
+def test_g10_oracle_nearest_hit_on_obj_meshes(golden_dir, name):
+    """Oracle traversal (SAH BVH over loader-built PreComputedTriangles, and brute force) against the reference's
+    triangle_intersect run over every triangle of the reference's own meshes."""
+    g = np.load(os.path.join(golden_dir, "g10_obj_meshes.npz"))
+    from light_transport_amd.src.io import triangles_from_mesh
+    from light_transport_amd.src import bvh_new as B, constants as K
+    v, f = g[name + "_verts"], g[name + "_faces"]
+    tris = triangles_from_mesh(v, f, K.GLASS_MAT, drop_degenerate=False)
+    for k, t in enumerate(tris):
+        t.face_index = k
+    ordered, linear = B.build_linear_bvh(tris, 0)
+    back = np.array([t.face_index for t in ordered])
+    mesh = dict(verts=B.triangles_array(ordered), med_front=np.zeros(len(ordered), np.int32),
+                med_back=np.zeros(len(ordered), np.int32), nodes=B.linear_bvh_arrays(linear))
+    sc = O.OracleScene([(0.1, 1.0, 0.0, 1.0)], (4, 4, 4), (0, 0, 0), (1, 1, 1), mesh=mesh)
+    tri_xyz = v[f]
+    for use_bvh in (True, False):
+        prim, t = sc.intersect_rays(g[name + "_origins"], g[name + "_dirs"], None, use_bvh=use_bvh)
+        got = np.where(prim >= 0, back[np.maximum(prim, 0)], -1)
+        S.check_hits_against_fixture(got, t, g[name + "_prim"], g[name + "_t"], g[name + "_second"], tri_xyz)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference assets only exist in the build container")
+@pytest.mark.parametrize("name", ["teapot", "cow", "pumpkin"])
+def test_g10_loader_reads_the_reference_assets(golden_dir, name):
+    """src/io.read_obj on the reference's files == the fixture's independently parsed vertices and faces."""
+    g = np.load(os.path.join(golden_dir, "g10_obj_meshes.npz"))
+    from light_transport_amd.src.io import read_obj, load_obj
+    path = "/root/reference/LightTransportSimulator/light_transport/examples/obj/%s.obj" % name
+    v, f = read_obj(path)
+    assert np.array_equal(v, g[name + "_verts"])
+    nz = np.einsum("ij,ij->i", *(2 * [np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])])) > 0
+    assert np.array_equal(f[nz], g[name + "_faces"])
+    objects, dimension = load_obj(path)
+    assert len(objects) == len(g[name + "_faces"]) and dimension == abs(v.max())
