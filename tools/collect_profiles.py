@@ -27,7 +27,12 @@ for d in ("fetch", "write", "sq"):
     shutil.copy(f, os.path.join(P, "%s_%s_pmc_%s.csv" % (tag, workload, d)))
     rows = [r for r in csv.DictReader(open(f)) if "walk_kernel" in r["Kernel_Name"] or "k_log_" in r["Kernel_Name"] or "k_grid_add" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    last_walk = max(int(r["Dispatch_Id"]) for r in rows if "walk_kernel" in r["Kernel_Name"])
+    # the PMC passes run `bench.py --inflight 1 --overlap 1 --steps 2 --warmup 1 --no-alone`: 3 launches of b batches
+    # each (+ the pilot batch of the first): the last launch = the last b walk dispatches and everything after the
+    # first of them
+    walks = [int(r["Dispatch_Id"]) for r in rows if "walk_kernel" in r["Kernel_Name"] and r["Counter_Name"] == rows[0]["Counter_Name"]]
+    b = max(1, (len(walks) - 1) // 3)
+    last_walk = sorted(walks)[-b]
     for r in rows:
         if int(r["Dispatch_Id"]) >= last_walk:
             kn = r["Kernel_Name"]

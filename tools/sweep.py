@@ -6,9 +6,10 @@ import light_transport_amd as lt
 from tests import scenes as S
 
 ctx = lt.Context(0)
-def run(prob, n, dtype, f32, bpc=0, thr=0, reps=3, label=""):
+def run(prob, n, dtype, f32, bpc=0, thr=0, reps=3, label="", lanes=1):
     prob.apply(ctx, dtype)
     ctx.set_launch_config(bpc, thr)
+    ctx.set_overlap(lanes)
     best = 1e9
     for r in range(reps):
         ctx.zero_tally(); ctx.launch(n, seed=r, f32_walk=f32); ctx.sync()
@@ -41,9 +42,11 @@ if which in ("all", "configs"):
     run(S.two_layer(n=512, voxel=0.025), 12500000, "f64", False, label="C5 per-GPU share 512^3", reps=3)
     run(S.two_layer(n=512, voxel=0.025), 12500000, "f32", True, label="C5 per-GPU share 512^3", reps=3)
 if which == "modes":
-    for mode in ("atomic", "log"):
+    for mode, lanes in (("atomic", 1), ("log", 1), ("log", 2)):
         ctx.set_tally_mode(mode)
-        print("== tally mode", mode, flush=True)
+        print("== tally mode", mode, "lanes per launch", lanes, flush=True)
+        import functools
+        run = functools.partial(run, lanes=lanes) if not isinstance(run, functools.partial) else functools.partial(run.func, lanes=lanes)
         run(S.slab(n=64, voxel=0.4), 10**7, "f64", False, label="C1-geometry 1e7 64^3")
         run(c2, 10**7, "f64", False, label="C2")
         run(c2, 10**7, "f32", True, label="C2")
