@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 1
+#define LT_ABI_VERSION 2
 
 /* error codes */
 #define LT_OK 0
@@ -314,7 +314,16 @@ int lt_render_surface_old(lt_ctx* ctx, int width, int height, int samples, int m
 typedef struct lt_vertex {
     double point[3];     /* Vertex.point                                              */
     double direction[3]; /* direction of travel on arrival                            */
+    double g_norm[3];    /* Vertex.g_norm: the light's normal (light_samples.py:104) / the interface normal facing
+                            the arriving photon; zero inside a medium (bdpt.py:275: "on a surface if non-zero") */
     double throughput;   /* photon weight on arrival (Vertex.throughput, scalar)      */
+    double pdf_pos;      /* emission vertex: 1 / light area (light_samples.py:100); pencil beam: 1; else 0 */
+    double pdf_dir;      /* density of the direction the path LEAVES this vertex in: emission -- |cos| / pi
+                            (light_samples.py:83), pencil beam: 1; medium -- the Henyey-Greenstein value
+                            (medium_samples.py:14-16) of the sampled deflection; interface (a delta event) -- the
+                            probability of the branch taken, R or 1 - R; 0 when the path ends here.  A path's
+                            pdf_fwd[k] = pdf_dir[k-1] and pdf_rev[k] = pdf_dir[k+1] (bdpt.py:25-27,137; both
+                            distributions are symmetric), in solid-angle measure                           */
     int32_t kind;        /* LT_VERTEX_* (Vertex.medium)                               */
     int32_t medium;      /* layer index (slabs) / medium id (meshes) on arrival       */
     uint32_t step;       /* photon-step index of the event (0 = emission)             */

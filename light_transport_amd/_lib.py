@@ -32,9 +32,10 @@ SYMBOLS = [
     "lt_last_log_info",
 ]
 
-# lt_vertex as a NumPy record (72 bytes, same layout as the C struct)
-VERTEX_DTYPE = np.dtype([("point", "<f8", 3), ("direction", "<f8", 3), ("throughput", "<f8"), ("kind", "<i4"),
-                         ("medium", "<i4"), ("step", "<u4"), ("pad_", "<u4")])
+# lt_vertex as a NumPy record (112 bytes, same layout as the C struct)
+VERTEX_DTYPE = np.dtype([("point", "<f8", 3), ("direction", "<f8", 3), ("g_norm", "<f8", 3), ("throughput", "<f8"),
+                         ("pdf_pos", "<f8"), ("pdf_dir", "<f8"), ("kind", "<i4"), ("medium", "<i4"), ("step", "<u4"),
+                         ("pad_", "<u4")])
 VERTEX_LIGHT, VERTEX_REFLECTIVE, VERTEX_TRANSMISSIVE, VERTEX_VOLUME = 5, 3, 4, 7
 
 

@@ -538,13 +538,15 @@ template <typename T> LT_DEV T wave_sum(T v)
 // light sub-path capture (f4): store vertex k of photon `rel` while k < max_vertices
 template <typename R>
 LT_DEV void record_vertex(const WalkParams& P, unsigned long long rel, unsigned& nv, R px, R py, R pz, R ux, R uy,
-                          R uz, R w, int kind, int medium, unsigned step)
+                          R uz, R w, int kind, int medium, unsigned step, R gx, R gy, R gz, R pdf_pos, R pdf_dir)
 {
     if (nv < P.max_vertices) {
         lt_vertex* v = P.vertices + rel * (unsigned long long)P.max_vertices + nv;
         v->point[0] = (double)px; v->point[1] = (double)py; v->point[2] = (double)pz;
         v->direction[0] = (double)ux; v->direction[1] = (double)uy; v->direction[2] = (double)uz;
-        v->throughput = (double)w; v->kind = kind; v->medium = medium; v->step = step; v->pad_ = 0;
+        v->g_norm[0] = (double)gx; v->g_norm[1] = (double)gy; v->g_norm[2] = (double)gz;
+        v->throughput = (double)w; v->pdf_pos = (double)pdf_pos; v->pdf_dir = (double)pdf_dir;
+        v->kind = kind; v->medium = medium; v->step = step; v->pad_ = 0;
         nv++;
         P.vertex_counts[rel] = nv;
     }

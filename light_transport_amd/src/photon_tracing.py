@@ -176,7 +176,12 @@ def generate_light_subpaths(tracer, n_photons, max_depth, seed=0, photon_offset=
     if not as_objects:
         return rec, cnt
     from .vertex import Vertex
-    return [[Vertex.from_record(rec[i, k]) for k in range(int(cnt[i]))] for i in range(int(n_photons))]
+    out = []
+    for i in range(int(n_photons)):
+        m = int(cnt[i])
+        out.append([Vertex.from_record(rec[i, k], rec[i, k - 1] if k > 0 else None, rec[i, k + 1] if k + 1 < m else None)
+                    for k in range(m)])
+    return out
 
 
 def fluence(absorbed, mu_a, voxel_volume, n_photons):

@@ -17,8 +17,9 @@ _LIB = None
 FN = dict(HG_PDF=0, HG_SAMPLE=1, ONB=2, DISK=3, COSINE_HEMI=4, REFLECT=5, BOUNDARY=6, SPIN=7)
 _FN_SHAPE = {0: (2, 1), 1: (2, 1), 2: (3, 6), 3: (2, 2), 4: (8, 4), 5: (6, 3), 6: (8, 5), 7: (5, 3)}
 FX_SCALE = 2.0 ** 40
-VERTEX_DTYPE = np.dtype([("point", "<f8", 3), ("direction", "<f8", 3), ("throughput", "<f8"), ("kind", "<i4"),
-                         ("medium", "<i4"), ("step", "<u4"), ("pad_", "<u4")])
+VERTEX_DTYPE = np.dtype([("point", "<f8", 3), ("direction", "<f8", 3), ("g_norm", "<f8", 3), ("throughput", "<f8"),
+                         ("pdf_pos", "<f8"), ("pdf_dir", "<f8"), ("kind", "<i4"), ("medium", "<i4"), ("step", "<u4"),
+                         ("pad_", "<u4")])
 
 
 class Medium(C.Structure):

@@ -595,6 +595,7 @@ def test_light_subpath_vertices(ctx, name):
     g, c = ctx.read_grid(), ctx.read_counters()
     v, cnt = ctx.read_vertices(n)
     ctx.set_vertex_capture(0)
+    from light_transport_amd import _lib as _kinds
     go, co, vo, cnto = prob.oracle().run_capture(n, K, seed=31)
     check_counters(c, co, n)
     S.assert_grid_close(g, go)
@@ -606,6 +607,25 @@ def test_light_subpath_vertices(ctx, name):
     np.testing.assert_allclose(v["point"][live], vo["point"][live], rtol=0, atol=1e-10)
     np.testing.assert_allclose(v["direction"][live], vo["direction"][live], rtol=0, atol=1e-11)
     np.testing.assert_allclose(v["throughput"][live], vo["throughput"][live], rtol=1e-12)
+    # the fields the reference's walk fills (light_samples.py:100-114, bdpt.py:25-27,137): geometric normal, emission
+    # densities, density of the outgoing direction
+    np.testing.assert_allclose(v["g_norm"][live], vo["g_norm"][live], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(v["pdf_pos"][live], vo["pdf_pos"][live], rtol=1e-13)
+    np.testing.assert_allclose(v["pdf_dir"][live], vo["pdf_dir"][live], rtol=1e-9, atol=1e-13)
+    vol, dlt = v["kind"] == _kinds.VERTEX_VOLUME, (v["kind"] == _kinds.VERTEX_REFLECTIVE) | (v["kind"] == _kinds.VERTEX_TRANSMISSIVE)
+    assert np.all(v["g_norm"][live & vol] == 0) and np.allclose(np.linalg.norm(v["g_norm"][live & dlt], axis=-1), 1.0)
+    assert np.all((v["pdf_dir"][live & dlt] >= 0) & (v["pdf_dir"][live & dlt] <= 1))          # a branch probability
+    if name == "cornell":      # quad light 2 x 2: pdf_pos = 1/4, pdf_dir = cos / pi about the normal (0, -1, 0)
+        assert np.allclose(v["pdf_pos"][:, 0], 0.25)
+        np.testing.assert_allclose(v["pdf_dir"][:, 0], -v["direction"][:, 0, 1] / np.pi, rtol=1e-12)
+    else:                      # pencil beam: a delta source
+        assert np.all(v["pdf_pos"][:, 0] == 1.0) and np.all(v["pdf_dir"][:, 0] == 1.0)
+    # Henyey-Greenstein value of the deflection actually taken: cos = d_in . d_out between consecutive vertices
+    from light_transport_amd.src.medium_samples import henyey_greenstein
+    k0 = np.flatnonzero((cnt >= 3) & vol[:, 1] & (v["pdf_dir"][:, 1] > 0))[:200]
+    cosd = np.einsum("ij,ij->i", v["direction"][k0, 1], v["direction"][k0, 2])
+    gs = np.array([prob.media[m][2] for m in (v["medium"][k0, 1] if name == "cornell" else np.array(prob.layers["medium_idx"])[v["medium"][k0, 1]])])
+    np.testing.assert_allclose(v["pdf_dir"][k0, 1], [henyey_greenstein(-c, g) for c, g in zip(cosd, gs)], rtol=1e-9)
     from light_transport_amd import _lib
     assert np.all(v["kind"][:, 0] == _lib.VERTEX_LIGHT) and np.all(v["step"][:, 0] == 0)
     kinds = set(np.unique(v["kind"][live]))
@@ -616,6 +636,9 @@ def test_light_subpath_vertices(ctx, name):
     paths = PT.generate_light_subpaths(tr, 50, 5, seed=31, as_objects=True)
     assert len(paths) == 50 and all(1 <= len(p) <= 5 for p in paths) and paths[0][0].hit_light
     np.testing.assert_allclose(paths[7][1].point, v["point"][7, 1], atol=1e-12)
+    assert paths[7][1].pdf_fwd == paths[7][0].pdf_dir and (len(paths[7]) < 3 or paths[7][1].pdf_rev == paths[7][2].pdf_dir)
+    from light_transport_amd.src.vertex import convert_density
+    assert convert_density(paths[7][1].pdf_fwd, paths[7][0], paths[7][1]) > 0
     with pytest.raises(Exception):
         ctx.read_vertices(n)       # nothing captured by the last launch
     # a capture size changed AFTER the capturing launch must not resize the read (it would read out of bounds)

@@ -35,7 +35,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(L, n), "missing export " + n
     assert sorted(_lib.SYMBOLS) == names
-    assert L.lt_abi_version() == 1
+    assert L.lt_abi_version() == 2
 
 
 def test_no_cpu_fallback_create_fails_loudly():
