@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -1097,17 +1098,21 @@ int lt_reduce_grid(lt_ctx* c, void* comm, int root)
     CHECK_CTX(c);
     if (!comm) return c->fail(LT_E_INVALID, "lt_reduce_grid: null communicator");
     if (!c->have_grid) return c->fail(LT_E_STATE, "lt_reduce_grid: no grid");
-    if (!g_rccl.h) {
-        g_rccl.h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!g_rccl.h) g_rccl.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!g_rccl.h) return c->fail(LT_E_UNSUPPORTED, "lt_reduce_grid: cannot load librccl.so: %s", dlerror());
-        g_rccl.allreduce = (nccl_allreduce_t)dlsym(g_rccl.h, "ncclAllReduce");
-        g_rccl.reduce = (nccl_reduce_t)dlsym(g_rccl.h, "ncclReduce");
-        g_rccl.gstart = (nccl_group_t)dlsym(g_rccl.h, "ncclGroupStart");
-        g_rccl.gend = (nccl_group_t)dlsym(g_rccl.h, "ncclGroupEnd");
-        if (!g_rccl.allreduce || !g_rccl.reduce || !g_rccl.gstart || !g_rccl.gend)
-            return c->fail(LT_E_UNSUPPORTED, "lt_reduce_grid: librccl.so lacks ncclAllReduce/ncclReduce");
-    }
+    // contexts are independent across threads (lt.h): the library is loaded exactly once
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        g_rccl.allreduce = (nccl_allreduce_t)dlsym(h, "ncclAllReduce");
+        g_rccl.reduce = (nccl_reduce_t)dlsym(h, "ncclReduce");
+        g_rccl.gstart = (nccl_group_t)dlsym(h, "ncclGroupStart");
+        g_rccl.gend = (nccl_group_t)dlsym(h, "ncclGroupEnd");
+        g_rccl.h = h;
+    });
+    if (!g_rccl.h) return c->fail(LT_E_UNSUPPORTED, "lt_reduce_grid: cannot load librccl.so");
+    if (!g_rccl.allreduce || !g_rccl.reduce || !g_rccl.gstart || !g_rccl.gend)
+        return c->fail(LT_E_UNSUPPORTED, "lt_reduce_grid: librccl.so lacks ncclAllReduce/ncclReduce");
     BIND(c);
     const int dt = c->tally == LT_TALLY_F32 ? kNcclFloat32 : (c->tally == LT_TALLY_F64 ? kNcclFloat64 : kNcclUint64);
     DevCounters* dc = (DevCounters*)c->d_counters.p;
