@@ -389,6 +389,9 @@ __global__ void __launch_bounds__(kPartThreads) k_log_count2(LogReduceParams L)
 
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kReduceThreads = 512;
+#ifndef LT_REDUCE_WAVES
+#define LT_REDUCE_WAVES 8     /* <= 64 VGPRs: the reduce workgroup (2 waves per SIMD) fits the 128 registers three walk waves leave */
+#endif
 
 template <typename TV, typename AT>
 __device__ __forceinline__ void add8(AT* s_tile, const uint4 q, const Quad<TV>& a, const Quad<TV>& b)
@@ -401,7 +404,7 @@ __device__ __forceinline__ void add8(AT* s_tile, const uint4 q, const Quad<TV>& 
 }
 
 template <typename TV>
-__global__ void __launch_bounds__(kReduceThreads) k_log_reduce(LogReduceParams L)
+__global__ void __launch_bounds__(kReduceThreads, LT_REDUCE_WAVES) k_log_reduce(LogReduceParams L)
 {
     typedef typename AccT<TV>::type AT;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];

@@ -17,6 +17,7 @@ def run(depth, tally="f64", f32=False, bpc=0):
     for c in ctxs:
         prob.apply(c, tally)
         c.set_tally_mode(1)
+        c.set_overlap(1)
         c.set_launch_config(bpc, 256 if bpc else 0)
         c.reserve_log(n)
         c.zero_tally(); c.launch(n, seed=99, f32_walk=f32); c.sync()      # warm-up: sizes the log
