@@ -788,6 +788,8 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     v.mesh = c->have_mesh ? 1 : 0;
     v.table = rng_table ? 1 : 0;
     v.tally = c->tally;
+    v.capture = c->max_vertices > 0 ? 1 : 0;
+    if (v.capture && (v.f32 || v.table)) return c->fail(LT_E_UNSUPPORTED, "lt_launch: vertex capture runs the f64 walk with the XORWOW generator");
     if (std::getenv("LT_DIAG_NO_TALLY")) v.tally = 3;  // diagnostic: time the walk without deposition
     if (v.table && v.f32) return c->fail(LT_E_UNSUPPORTED, "lt_launch: table RNG runs the f64 walk only");
     if (v.table && v.tally == LT_TALLY_F32) return c->fail(LT_E_UNSUPPORTED, "lt_launch: table RNG needs an f64 or u64fx tally");

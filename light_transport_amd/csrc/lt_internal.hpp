@@ -117,6 +117,7 @@ struct Variant {
     int mesh;    // 0: layered slab, 1: mesh + BVH staged in LDS, 2: mesh + BVH read from global memory
     int table;   // 0: XORWOW, 1: table RNG
     int tally;   // LT_TALLY_*
+    int capture; // 1: the build that stores light sub-path vertices (f64 walk, XORWOW)
 };
 
 hipError_t launch_walk(const WalkParams& P, const Variant& v, const LaunchCfg& cfg, hipStream_t s);

@@ -638,38 +638,43 @@ constexpr unsigned kQueryMin = LT_QUERY_MIN;     // mesh walks: lanes a wave col
 // ---------------------------------------------------------------------------
 typedef void (*WalkFn)(const WalkParams);
 
-template <typename R, int GEOM, bool TABLE>
+// CAPTURE (light sub-path vertices, f4) is a compile-time variant: the capture code costs the plain walk registers
+// even behind a never-taken branch (36-84 B of scratch per lane, walk 29.7 -> 34.6 ms when it was a run-time test).
+// Captures run the f64 walk with the XORWOW generator.
+template <typename R, int GEOM, bool TABLE, bool CAPTURE>
 static WalkFn pick_tally(int tally)
 {
     switch (tally) {
     // slabs: walk_kernel; meshes: walk_kernel_q (the same body with batched BVH queries, lt_walk_kernel.inc)
     case LT_TALLY_F32:
         if constexpr (TABLE) return nullptr;
-        else if constexpr (GEOM == 0) return walk_kernel<R, GEOM, TABLE, LT_TALLY_F32>;
-        else return walk_kernel_q<R, GEOM, TABLE, LT_TALLY_F32>;
+        else if constexpr (GEOM == 0) return walk_kernel<R, GEOM, TABLE, LT_TALLY_F32, CAPTURE>;
+        else return walk_kernel_q<R, GEOM, TABLE, LT_TALLY_F32, CAPTURE>;
     case LT_TALLY_F64:
-        if constexpr (GEOM == 0) return walk_kernel<R, GEOM, TABLE, LT_TALLY_F64>;
-        else return walk_kernel_q<R, GEOM, TABLE, LT_TALLY_F64>;
+        if constexpr (GEOM == 0) return walk_kernel<R, GEOM, TABLE, LT_TALLY_F64, CAPTURE>;
+        else return walk_kernel_q<R, GEOM, TABLE, LT_TALLY_F64, CAPTURE>;
     case LT_TALLY_U64FX:
-        if constexpr (GEOM == 0) return walk_kernel<R, GEOM, TABLE, LT_TALLY_U64FX>;
-        else return walk_kernel_q<R, GEOM, TABLE, LT_TALLY_U64FX>;
-    case LT_TALLY_NONE: if constexpr (!TABLE && GEOM == 0) return walk_kernel<R, GEOM, TABLE, LT_TALLY_NONE>; else return nullptr;
+        if constexpr (GEOM == 0) return walk_kernel<R, GEOM, TABLE, LT_TALLY_U64FX, CAPTURE>;
+        else return walk_kernel_q<R, GEOM, TABLE, LT_TALLY_U64FX, CAPTURE>;
+    case LT_TALLY_NONE:
+        if constexpr (!TABLE && GEOM == 0 && !CAPTURE) return walk_kernel<R, GEOM, TABLE, LT_TALLY_NONE, false>; else return nullptr;
     }
     return nullptr;
 }
 
-template <typename R, bool TABLE>
+template <typename R, bool TABLE, bool CAPTURE>
 static WalkFn pick_geom(const Variant& v)
 {
-    if (v.mesh == 0) return pick_tally<R, 0, TABLE>(v.tally);
-    if (v.mesh == 1) return pick_tally<R, 1, TABLE>(v.tally);
-    if constexpr (!TABLE) return pick_tally<R, 2, TABLE>(v.tally); else return nullptr;
+    if (v.mesh == 0) return pick_tally<R, 0, TABLE, CAPTURE>(v.tally);
+    if (v.mesh == 1) return pick_tally<R, 1, TABLE, CAPTURE>(v.tally);
+    if constexpr (!TABLE) return pick_tally<R, 2, TABLE, CAPTURE>(v.tally); else return nullptr;
 }
 
 static WalkFn pick(const Variant& v)
 {
-    if (v.f32) return v.table ? nullptr : pick_geom<float, false>(v);
-    return v.table ? pick_geom<double, true>(v) : pick_geom<double, false>(v);
+    if (v.capture) return (v.f32 || v.table) ? nullptr : pick_geom<double, false, true>(v);
+    if (v.f32) return v.table ? nullptr : pick_geom<float, false, false>(v);
+    return v.table ? pick_geom<double, true, false>(v) : pick_geom<double, false, false>(v);
 }
 
 size_t walk_lds_bytes(const Variant& v, int n_media, int n_layers, int n_tris, int n_nodes, unsigned n_hist)
