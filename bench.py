@@ -241,6 +241,19 @@ def main(argv=None):
                 c.reserve_log(per_gpu)    # scratch allocation is set-up, not part of a step (matters when --warmup 0)
         return cs
 
+    every = {"walk_ms": 0.0, "partition_ms": 0.0, "reduce_ms": 0.0, "batches": 0, "launches": 0}
+
+    def note(c):
+        """Stage sums of the launch that has just completed on c (HIP events on its streams): EVERY launch of this
+        process is counted -- probe, warm-up, timed and reference launches -- so that the per-dispatch averages can be
+        held against a rocprofv3 --kernel-trace --stats summary of the same command."""
+        st = c.last_log_stages()
+        if st is not None:
+            for k in ("walk_ms", "partition_ms", "reduce_ms", "batches"):
+                every[k] += st[k]
+            every["launches"] += 1
+        return st
+
     def run_jobs(cs, n, seed0):
         """n jobs over the contexts cs in turn, no collectives, host-timed: ms per job."""
         for c in cs:
@@ -253,7 +266,10 @@ def main(argv=None):
             c.zero_tally(); c.launch(per_gpu, seed=seed0 + k, photon_offset=offset, f32_walk=args.f32_walk)
         for c in cs:
             c.sync()
-        return (time.perf_counter() - t0) / n * 1e3
+        dt = (time.perf_counter() - t0) / n * 1e3
+        for k in range(n):          # (only the last launch of every context can still be read: count it for each job it stands for)
+            note(cs[k % len(cs)])
+        return dt
 
     probe = None
     if args.inflight == 2:
@@ -303,9 +319,9 @@ def main(argv=None):
         if distributed:
             reduce_ctx(c)
         c.sync()
+        st = note(c)
         if record:
             kernel_ms.append(c.last_kernel_ms())
-            st = c.last_log_stages()
             if st is not None:
                 stages.append(st)
             steps_per_launch.append(c.read_counters()["steps"])   # rank 0: the reduced sum; part of "tally readback"
@@ -346,7 +362,7 @@ def main(argv=None):
         for k in range(3):
             c.zero_tally(); c.launch(per_gpu, seed=500 + k, photon_offset=offset, f32_walk=args.f32_walk); c.sync()
             ms.append(c.last_kernel_ms())
-            st = c.last_log_stages()
+            st = note(c)
         alone = {"job_ms": float(np.mean(ms[1:]))}
         if st is not None:
             alone.update({k: st[k] for k in ("walk_ms", "scan_ms", "partition_ms", "reduce_ms")})
@@ -430,6 +446,18 @@ def main(argv=None):
                      "achieved": (rb_ - 2) * rec / (r_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (rb_ - 2) * rec / (r_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "note": "algorithmic: every record read once (%d B)" % (rb_ - 2)}]
+        if every["batches"]:
+            passes_ = 2 if wl["grid"] ** 3 > 1024 * 16384 else 1
+            out["roofline"]["all_dispatches_avg_ms"] = {
+                "walk_kernel": every["walk_ms"] / every["batches"],
+                "k_log_part (all passes of a batch)": every["partition_ms"] / every["batches"],
+                "k_log_reduce": every["reduce_ms"] / every["batches"],
+                "dispatches_per_kernel": every["batches"], "launches": every["launches"],
+                "note": "mean over EVERY dispatch this process made (probe, warm-up, timed, reference launches; sub-batches "
+                        "and pilot batches count as dispatches): the number a rocprofv3 --kernel-trace --stats summary of the "
+                        "same command reports as AverageNs (profiles/*_kernel_stats.csv); %s" % (
+                            "k_log_part<.,1> + k_log_count2 + k_log_part<.,2> are separate rows there" if passes_ == 2 else
+                            "one partition dispatch per batch")}
         if alone:
             alone["note"] = ("one job alone on the device, one lane (default launch geometry, 4 waves/SIMD), 2 launches after the "
                              "timed region: single-job latency and kernel durations nothing overlaps")

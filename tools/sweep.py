@@ -15,7 +15,7 @@ def run(prob, n, dtype, f32, bpc=0, thr=0, reps=3, label="", lanes=1):
         ctx.zero_tally(); ctx.launch(n, seed=r, f32_walk=f32); ctx.sync()
         best = min(best, ctx.last_kernel_ms())
     c = ctx.read_counters()
-    print("%-34s n=%.0e tally=%-5s walk=%s bpc=%d thr=%3d  %8.2f ms  %6.2f Gsteps/s  %5.1f steps/photon" % (
+    print("%-34s n=%.3g tally=%-5s walk=%s bpc=%d thr=%3d  %8.2f ms  %6.2f Gsteps/s  %5.1f steps/photon" % (
         label, n, dtype, "f32" if f32 else "f64", bpc, thr, best, c["steps"] / best / 1e6, c["steps"] / n), flush=True)
 
 c2 = S.slab(n=256, voxel=0.1)
