@@ -17,7 +17,7 @@
 // Memory access shape: every streaming load is 16 bytes per lane (a lane owns 4 consecutive record indices and the
 // 4 values that go with them; the reduce reads 8 packed 2-byte positions and 8 values per lane and keeps two such
 // groups in flight), regions start at multiples of 8 records so those loads are aligned, and two partition workgroups
-// (2 x 16 waves, <= 64 VGPRs) share a CU so that one's LDS sort runs under the other's loads and stores.
+// (2 x 8 waves, 64 VGPRs) share a CU so that one's LDS sort runs under the other's loads and stores.
 #include <hip/hip_runtime.h>
 
 #include <atomic>

@@ -75,9 +75,9 @@ class JobPipeline:
         of ``batch`` photons (default: n / (4 * depth)) that the contexts take in turn, each ACCUMULATING into its own
         grid, so that one batch's log reduction runs beside the next batch's walk.  Returns (grid, counters) summed
         over the contexts -- identical to a single launch for the integer tally and the counters' integer fields,
-        equal up to summation order otherwise.  The overlap pays for grids of up to ~2000 tiles (256^3: 1024); at
-        512^3 the walk's per-workgroup tile histogram (64 KiB of LDS) leaves no room for a partition workgroup beside
-        it and the time equals a single launch's (tools/big_job.py: 0.59 s either way for config 5's 10^8 photons)."""
+        equal up to summation order otherwise.  (Since lt_set_overlap a single ``launch`` does this by itself, on two
+        streams of ONE context and into one grid; ``trace`` remains for hosts that want the batches on separate
+        contexts.)"""
         if self._pending:
             raise RuntimeError("trace() needs an idle pipeline: drain() first")
         n_photons = int(n_photons)

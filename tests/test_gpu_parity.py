@@ -753,6 +753,28 @@ def test_config5_geometry_512_cubed(ctx):
     ctx.set_grid((8, 8, 8), (0, 0, 0), (1, 1, 1), "f64")     # release the 1 GiB grid of the session ctx
 
 
+def test_overlap_auto_tries_both_regimes_then_keeps_one(ctx):
+    """lt_set_overlap(0): launches of >= 2^21 photons whose geometry is not pinned run once with two lanes, once with
+    one, then with whichever took less device time per photon; results do not depend on it (bit-identical u64 grids)."""
+    prob = S.slab(n=128, voxel=0.2)
+    n = (1 << 21) + 20000
+    prob.apply(ctx, "u64fx"); ctx.set_tally_mode("log"); ctx.set_overlap(0)
+    lanes, grids = [], []
+    for k in range(5):
+        ctx.zero_tally(); ctx.launch(n, seed=3); ctx.sync()
+        lanes.append(ctx.last_log_info()["lanes"]); grids.append(ctx.read_grid_raw())
+    # (the first launch of a scene starts with the pilot batch: not a clean timing, so two lanes are measured again)
+    assert lanes[:3] == [2, 2, 1] and lanes[3] == lanes[4] and lanes[3] in (1, 2), lanes
+    assert all(np.array_equal(g, grids[0]) for g in grids[1:])
+    ctx.set_launch_config(4, 256)            # a pinned geometry keeps one lane
+    ctx.zero_tally(); ctx.launch(n, seed=3); ctx.sync()
+    assert ctx.last_log_info()["lanes"] == 1 and np.array_equal(ctx.read_grid_raw(), grids[0])
+    ctx.set_launch_config(0, 0)
+    ctx.zero_tally(); ctx.launch(100000, seed=3); ctx.sync()          # small launches stay on one lane
+    assert ctx.last_log_info()["lanes"] == 1
+    ctx.set_tally_mode("auto", 0)
+
+
 # ---------------------------------------------------------------- several jobs in flight on one GPU
 def test_job_pipeline_matches_single_context(ctx):
     """Two contexts taking jobs in turn (light_transport_amd.JobPipeline, what bench.py --inflight 2 does) return, in
