@@ -19,8 +19,9 @@ Regimes (how a rank keeps its GPU busy; results are identical):
   one_call      ONE context; every lt_launch is cut into sub-batches that alternate between the context's two lanes, so
                 that one batch's log reduction runs beside the next batch's walk (lt_set_overlap 2)      [--inflight 1]
   two_jobs      TWO contexts take the steps in turn (two complete jobs in flight)                         [--inflight 2]
+  three_jobs    THREE contexts (256^3 workloads: the logs of three jobs must fit)                         [--inflight 3]
   one_at_a_time ONE context, one lane: kernels strictly back to back                        [--inflight 1 --overlap 1]
-By default a short untimed probe runs all three and the timed region uses the fastest; the probe's numbers are reported.
+By default a short untimed probe runs all of them and the timed region uses the fastest; the probe's numbers are reported.
 
 Prints ONE JSON line on rank 0:  metric = photon-steps/s over all ranks, plus
   roofline      algorithmic tally bytes (16 B per photon-step for the f64 tally: 8 B read + 8 B write of one voxel)
@@ -172,7 +173,7 @@ def main(argv=None):
     ap.add_argument("--tally-mode", default="log", choices=["log", "atomic", "auto"],
                     help="log: deposit log + tile partition + LDS reduce (default); atomic: one global atomic per deposit")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="contexts taking the steps in turn: 2 = two jobs in flight, 1 = one context; 0 (default) = an "
+                    help="contexts taking the steps in turn: 2 / 3 = that many jobs in flight, 1 = one context; 0 (default) = an "
                          "untimed probe picks the fastest regime")
     ap.add_argument("--overlap", type=int, default=-1,
                     help="lanes inside one launch (lt_set_overlap) for --inflight 1: 2 = one_call, 1 = one_at_a_time")
@@ -224,19 +225,23 @@ def main(argv=None):
         c.set_tally_mode(args.tally_mode)
         return c
 
-    ctx_a, ctx_b = new_ctx(), None
-    REGIMES = {"one_call": (1, 2), "two_jobs": (2, 1), "one_at_a_time": (1, 1)}   # name -> (contexts, lanes per launch)
+    pool = [new_ctx()]           # contexts, created when a regime first needs them
+    # name -> (contexts taking the jobs in turn, lanes per launch).  three_jobs: while one job reduces, TWO walks keep all
+    # four waves per SIMD busy (C2: 35.8 against 37.0 ms with two jobs); its three deposit logs only fit beside the
+    # other regimes' buffers for the 256^3 workload
+    REGIMES = {"one_call": (1, 2), "two_jobs": (2, 1), "one_at_a_time": (1, 1)}
+    if wl["grid"] <= 256:
+        REGIMES["three_jobs"] = (3, 1)
 
     def apply_regime(name):
-        nonlocal ctx_b
         depth, lanes = REGIMES[name]
-        if depth == 2 and ctx_b is None:
-            ctx_b = new_ctx()
-        cs = [ctx_a, ctx_b][:depth]
+        while len(pool) < depth:
+            pool.append(new_ctx())
+        cs = pool[:depth]
         for c in cs:
             c.set_overlap(lanes)
-            # two jobs in flight: each job's walk takes half of the resident workgroups (f64: 2 of 4 per CU; f32: 3 of 5)
-            c.set_launch_config(((3 if args.f32_walk else 2) if depth == 2 else 0), 256 if depth == 2 else 0)
+            # jobs in flight: each job's walk takes half of the resident workgroups (f64: 2 of 4 per CU; f32: 3 of 5)
+            c.set_launch_config(((3 if args.f32_walk else 2) if depth >= 2 else 0), 256 if depth >= 2 else 0)
             if args.tally_mode != "atomic":
                 c.reserve_log(per_gpu)    # scratch allocation is set-up, not part of a step (matters when --warmup 0)
         return cs
@@ -255,24 +260,30 @@ def main(argv=None):
         return st
 
     def run_jobs(cs, n, seed0):
-        """n jobs over the contexts cs in turn, no collectives, host-timed: ms per job."""
+        """n complete jobs over the contexts cs in turn -- for N > 1 INCLUDING each job's reduce to rank 0, exactly as the
+        timed region runs them (the regimes differ in how many streams they keep busy beside RCCL's) -- host-timed: ms
+        per job.  Every rank runs the same sequence, so the collectives pair up."""
         for c in cs:
             c.sync()
         t0 = time.perf_counter()
         for k in range(n):
             c = cs[k % len(cs)]
             if k >= len(cs):
-                c.sync()
+                if distributed:
+                    reduce_ctx(c)
+                c.sync(); note(c)
             c.zero_tally(); c.launch(per_gpu, seed=seed0 + k, photon_offset=offset, f32_walk=args.f32_walk)
-        for c in cs:
-            c.sync()
-        dt = (time.perf_counter() - t0) / n * 1e3
-        for k in range(n):          # (only the last launch of every context can still be read: count it for each job it stands for)
-            note(cs[k % len(cs)])
-        return dt
+        for k in range(max(0, n - len(cs)), n):
+            c = cs[k % len(cs)]
+            if distributed:
+                reduce_ctx(c)
+            c.sync(); note(c)
+        return (time.perf_counter() - t0) / n * 1e3
 
     probe = None
-    if args.inflight == 2:
+    if args.inflight == 3:
+        regime = "three_jobs"
+    elif args.inflight == 2:
         regime = "two_jobs"
     elif args.inflight == 1:
         regime = "one_at_a_time" if args.overlap == 1 else "one_call"
@@ -282,7 +293,9 @@ def main(argv=None):
         # Untimed probe: which regime keeps THIS device busiest?  (Two streams only overlap when the runtime gives them
         # separate hardware queues -- see GPU_MAX_HW_QUEUES above -- so it is measured, not assumed.)
         probe = {}
-        for name in ("one_at_a_time", "one_call", "two_jobs"):
+        for name in ("one_at_a_time", "one_call", "two_jobs", "three_jobs"):
+            if name not in REGIMES:
+                continue
             cs = apply_regime(name)
             run_jobs(cs, len(cs), 900)                    # sizes the logs, pilot batch of a new scene
             probe[name + "_ms"] = run_jobs(cs, 2 * len(cs), 910)
@@ -295,8 +308,8 @@ def main(argv=None):
         probe["chosen"] = regime
     ctxs = apply_regime(regime)
     depth, lanes = REGIMES[regime]
-    if depth == 1 and ctx_b is not None:
-        ctx_b.close(); ctx_b = None
+    while len(pool) > depth:         # contexts the chosen regime does not use give their logs back
+        pool.pop().close()
     info = ctxs[0].device_info()
 
     def barrier():
@@ -474,9 +487,8 @@ def main(argv=None):
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
-    for c in [ctx_a, ctx_b]:
-        if c is not None:
-            c.close()
+    for c in pool:
+        c.close()
 
 
 if __name__ == "__main__":

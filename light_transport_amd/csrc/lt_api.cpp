@@ -481,6 +481,7 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         // update "their" voxels with plain read-add-writes, and a walk's overflow atomics never race with the other
         // lane's reduce
         const size_t gb = c->n_vox() * c->grid_elem();
+        if (!c->lanes[1].stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->lanes[1].stream, hipStreamNonBlocking));
         HIP_TRY(c, c->d_grid1.ensure(gb));
         HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->lanes[1].stream, c->ev_fork, 0));
@@ -601,8 +602,8 @@ int lt_create(lt_ctx** out, int device_id)
         c->log_budget = c->default_log_budget = quarter < ((size_t)64 << 30) ? quarter : ((size_t)64 << 30);
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->lanes[1].stream, hipStreamNonBlocking);
-    c->lanes[0].stream = c->stream;
+    c->lanes[0].stream = c->stream;      // (lane 1's stream is created when a launch first overlaps: a process's streams
+                                         //  share GPU_MAX_HW_QUEUES hardware queues, idle ones included)
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);

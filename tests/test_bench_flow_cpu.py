@@ -26,7 +26,7 @@ def run_bench(tmp_path, extra, nproc=2):
     return json.loads(lines[0]), calls
 
 
-@pytest.mark.parametrize("regime,flags", [("two_jobs", ["--inflight", "2"]), ("one_call", ["--inflight", "1"]),
+@pytest.mark.parametrize("regime,flags", [("two_jobs", ["--inflight", "2"]), ("three_jobs", ["--inflight", "3"]), ("one_call", ["--inflight", "1"]),
                                           ("one_at_a_time", ["--inflight", "1", "--overlap", "1"]), ("probe", [])])
 def test_bench_control_flow_world_size_2(tmp_path, regime, flags):
     K, W, n = 5, 2, 1000
@@ -37,7 +37,7 @@ def test_bench_control_flow_world_size_2(tmp_path, regime, flags):
     chosen = out["config"]["regime"]
     if regime == "probe":
         assert out["config"]["regime_probe"]["chosen"] == chosen
-        assert {"one_call_ms", "two_jobs_ms", "one_at_a_time_ms"} <= set(out["config"]["regime_probe"])
+        assert {"one_call_ms", "two_jobs_ms", "three_jobs_ms", "one_at_a_time_ms"} <= set(out["config"]["regime_probe"])
     else:
         assert chosen == regime and out["config"]["regime_probe"] is None
     # value = photon-steps of ALL ranks (reduced to rank 0) / wall: the fake job reports 281 * n + seed steps per rank
@@ -55,7 +55,8 @@ def test_bench_control_flow_world_size_2(tmp_path, regime, flags):
         assert sorted(c["seed"] for c in timed) == list(timed_seeds)                   # EXACTLY K timed steps
         assert len([c for c in launches if 1000 <= c["seed"] < 1000 + W]) == W       # W warm-up steps
         reduces = [c for c in cl if c["op"] == "reduce"]
-        assert len(reduces) == K + W                                                   # one reduce per job, none in the probe
+        probe_jobs = len([c for c in launches if 900 <= c["seed"] < 1000])             # the probe's jobs are reduced too
+        assert len(reduces) == K + W + probe_jobs                                      # exactly one reduce per job
         # on every context: zero_tally -> launch -> reduce -> (sync) before the next launch
         state = {}
         for c in cl:
@@ -66,7 +67,7 @@ def test_bench_control_flow_world_size_2(tmp_path, regime, flags):
                 assert state.get(c["ctx"]) == "flying"
             elif c["op"] == "sync":
                 state[c["ctx"]] = "idle"
-    depth = {"two_jobs": 2, "one_call": 1, "one_at_a_time": 1}[chosen]
+    depth = {"three_jobs": 3, "two_jobs": 2, "one_call": 1, "one_at_a_time": 1}[chosen]
     assert out["config"]["jobs_in_flight"] == depth
     timed_ctx = {c["ctx"] for c in calls[0] if c["op"] == "launch" and c["seed"] < K}
     assert len(timed_ctx) == depth
