@@ -51,6 +51,9 @@ struct DevBuf {
 // One lane of the log pipeline: a stream with its own deposit log, ping-pong copy and bookkeeping tables.  A launch
 // uses lane 0 (the ctx stream) alone, or alternates its batches between lanes 0 and 1 so that the bandwidth-bound
 // reduction of one batch runs beside the VALU-bound walk of the next (lt_set_overlap).
+constexpr int kMaxLanes = 3;      // lanes a launch may be spread over (lt_set_overlap)
+constexpr int kAutoLanes = 2;     // auto mode tries 1 and 2: a third lane measured no gain (profiles/r02c_lanes_1_2_3.log)
+
 struct LogLane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_done = nullptr;          // end of the lane's last batch
@@ -102,7 +105,7 @@ struct lt_ctx {
     size_t log_budget = (size_t)16 << 30, default_log_budget = (size_t)16 << 30;   // bytes for the logs and their ping-pong copies
     double rec_per_photon = 0.0;        // measured deposit records per photon (sizes the logs and the batches)
     int overlap_mode = 0;               // lt_set_overlap: 0 auto, 1 one lane, 2 two lanes
-    double auto_ms_per_photon[2] = {0.0, 0.0};   // overlap auto: device time per photon measured with 1 / 2 lanes
+    double auto_ms_per_photon[kMaxLanes] = {0.0, 0.0, 0.0};   // overlap auto: device time per photon measured with 1 / 2 / 3 lanes
     int auto_pending = -1;              // which of the two the launch in flight is measuring (-1: none)
     uint64_t captured_photons = 0;
     int blocks_per_cu = 0, threads_per_block = 0;
@@ -110,11 +113,11 @@ struct lt_ctx {
     // device buffers
     DevBuf d_media[2], d_zb[2], d_lm, d_tris[2], d_nodes[2];  // [0]=f64, [1]=f32
     DevBuf d_grid, d_counters, d_head, d_table, d_scratch_in, d_scratch_out, d_scratch_aux;
-    DevBuf d_mats, d_lights, d_r0, d_r1, d_lc, d_img, d_xy, d_vtx, d_vcnt, d_clear, d_job, d_grid1;   // d_grid1: lane 1's private grid
+    DevBuf d_mats, d_lights, d_r0, d_r1, d_lc, d_img, d_xy, d_vtx, d_vcnt, d_clear, d_job, d_gridx[kMaxLanes - 1];   // d_gridx: private grids of lanes 1, 2
     int cn[3] = {0, 0, 0};
     double corg[3] = {0, 0, 0}, ccell[3] = {1, 1, 1};
     bool have_clear = false;
-    LogLane lanes[2];
+    LogLane lanes[kMaxLanes];
     bool tables_dirty = true;
     bool timed = false;
 
@@ -135,7 +138,7 @@ struct lt_ctx {
     }
     size_t grid_elem() const { return tally == LT_TALLY_F32 ? 4 : 8; }
     size_t n_vox() const { return (size_t)nx * (size_t)ny * (size_t)nz; }
-    void scene_changed() { rec_per_photon = 0.0; auto_ms_per_photon[0] = auto_ms_per_photon[1] = 0.0; auto_pending = -1; }
+    void scene_changed() { rec_per_photon = 0.0; for (double& a : auto_ms_per_photon) a = 0.0; auto_pending = -1; }
 };
 
 #define CHECK_CTX(c) do { if (!(c)) return LT_E_INVALID; } while (0)
@@ -328,7 +331,7 @@ size_t log_slack_records() { return (size_t)kTileAlign * kMaxLogTiles + (size_t)
 
 struct LogPlan {
     int lanes = 1;
-    uint32_t cap_chunks[2] = {0, 0};                   // log capacity each lane may use (allocation capped by the budget)
+    uint32_t cap_chunks[kMaxLanes] = {0, 0, 0};                   // log capacity each lane may use (allocation capped by the budget)
     std::vector<std::pair<int, uint64_t>> batches;     // (lane, photons), in launch order
 };
 
@@ -384,7 +387,7 @@ int plan_log(lt_ctx* c, uint64_t n, int lanes, LogPlan* plan)
     // overlapped launches: sub-batches per launch.  Every batch ends in a drain of its longest photons and the last
     // one's reduction has nothing to hide under: 4 measured best on C2 and on the 512^3 share (2: 43.2, 4: 41.9,
     // 8: 46.9, 16: 57 ms per C2 job)
-    int sub = 4;
+    int sub = lanes == 3 ? 6 : 4;
     if (const char* e = std::getenv("LT_OVERLAP_BATCHES")) { int v = std::atoi(e); if (v >= 2 && v <= 256) sub = v; }
     const uint64_t b_target = lanes == 1 ? n : (n + (uint64_t)sub - 1) / (uint64_t)sub;
     // every resident walk wave holds one partly filled chunk: that many chunks are claimed on top of the records' own
@@ -399,7 +402,7 @@ int plan_log(lt_ctx* c, uint64_t n, int lanes, LogPlan* plan)
     for (int l = 0; l < lanes; l++) {
         if (ensure_lane(c, c->lanes[l], want, per_lane, G) != hipSuccess) {
             (void)hipGetLastError();
-            for (int k = 0; k < 2; k++) c->lanes[k].release_log();
+            for (int k = 0; k < kMaxLanes; k++) c->lanes[k].release_log();
             return LT_E_NOMEM;
         }
         // honour the budget even when an earlier, larger allocation is still there
@@ -417,15 +420,15 @@ int plan_log(lt_ctx* c, uint64_t n, int lanes, LogPlan* plan)
     } else {
         uint64_t b = (double)b_target > fit ? (uint64_t)fit : b_target;
         if (b < 1) b = 1;
-        // lane 0 starts with half a batch so that the two lanes fall out of step: from then on one lane's reduction
-        // runs beside the other lane's walk
-        int l = 0;
-        uint64_t first = b / 2 > 0 ? b / 2 : 1;
+        // the lanes' first batches are b/L, 2b/L, ... b, so that they fall out of step: from then on one lane's
+        // reduction runs beside the other lanes' walks
+        int l = 0, first_round = lanes;
         while (left > 0) {
-            const uint64_t take = first ? (first < left ? first : left) : (b < left ? b : left);
-            first = 0;
+            uint64_t take = b;
+            if (first_round > 0) { take = b * (uint64_t)(l + 1) / (uint64_t)lanes; if (take < 1) take = 1; first_round--; }
+            if (take > left) take = left;
             plan->batches.emplace_back(l, take);
-            left -= take; l ^= 1;
+            left -= take; l = (l + 1) % lanes;
         }
     }
     return LT_OK;
@@ -438,11 +441,13 @@ int choose_lanes(lt_ctx* c, uint64_t n)
 {
     c->auto_pending = -1;
     if (c->overlap_mode == 1) return 1;
-    if (c->overlap_mode == 2) return n >= 8192 ? 2 : 1;
+    if (c->overlap_mode >= 2) return n >= 8192 ? c->overlap_mode : 1;
     if (c->blocks_per_cu > 0 || n < kOverlapMinPhotons) return 1;    // the caller pinned the launch geometry / small job
-    if (c->auto_ms_per_photon[1] <= 0.0) { c->auto_pending = 1; return 2; }
-    if (c->auto_ms_per_photon[0] <= 0.0) { c->auto_pending = 0; return 1; }
-    return c->auto_ms_per_photon[1] < c->auto_ms_per_photon[0] ? 2 : 1;
+    for (int k = kAutoLanes - 1; k >= 0; k--)
+        if (c->auto_ms_per_photon[k] <= 0.0) { c->auto_pending = k; return k + 1; }
+    int best = 0;
+    for (int k = 1; k < kAutoLanes; k++) if (c->auto_ms_per_photon[k] < c->auto_ms_per_photon[best]) best = k;
+    return best + 1;
 }
 
 struct LogRun {
@@ -473,19 +478,21 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
     if (resident <= 0) return c->fail(LT_E_HIP, "lt_launch: log-mode kernel not resident");
     // two lanes: each walk takes half of the resident workgroups, so that two walks together fill the register file
     // and one walk leaves room for the other lane's partition / reduce workgroups
-    int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (plan.lanes == 2 ? (resident + 1) / 2 : resident);
-    if (plan.lanes == 2) if (const char* e = std::getenv("LT_OVERLAP_WALK_BPC")) { int v_ = std::atoi(e); if (v_ >= 1 && v_ <= 8) per_cu = v_; }
+    int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (plan.lanes >= 2 ? (resident + 1) / 2 : resident);
+    if (plan.lanes >= 2) if (const char* e = std::getenv("LT_OVERLAP_WALK_BPC")) { int v_ = std::atoi(e); if (v_ >= 1 && v_ <= 8) per_cu = v_; }
     const unsigned long long cap = (unsigned long long)per_cu * (unsigned long long)c->prop.multiProcessorCount;
-    if (plan.lanes == 2) {
-        // lane 1 tallies into a grid of its own (zeroed here, added to the ctx grid at the join): both lanes can then
-        // update "their" voxels with plain read-add-writes, and a walk's overflow atomics never race with the other
-        // lane's reduce
+    if (plan.lanes >= 2) {
+        // lanes 1, 2 tally into grids of their own (zeroed here, added to the ctx grid at the join): every lane can then
+        // update "its" voxels with plain read-add-writes, and a walk's overflow atomics never race with another lane's
+        // reduce
         const size_t gb = c->n_vox() * c->grid_elem();
-        if (!c->lanes[1].stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->lanes[1].stream, hipStreamNonBlocking));
-        HIP_TRY(c, c->d_grid1.ensure(gb));
         HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->lanes[1].stream, c->ev_fork, 0));
-        HIP_TRY(c, hipMemsetAsync(c->d_grid1.p, 0, gb, c->lanes[1].stream));
+        for (int l = 1; l < plan.lanes; l++) {
+            if (!c->lanes[l].stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->lanes[l].stream, hipStreamNonBlocking));
+            HIP_TRY(c, c->d_gridx[l - 1].ensure(gb));
+            HIP_TRY(c, hipStreamWaitEvent(c->lanes[l].stream, c->ev_fork, 0));
+            HIP_TRY(c, hipMemsetAsync(c->d_gridx[l - 1].p, 0, gb, c->lanes[l].stream));
+        }
     }
     for (const auto& bt : plan.batches) {
         LogLane& ln = c->lanes[bt.first];
@@ -493,7 +500,7 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         uint32_t* meta = (uint32_t*)ln.meta.p;
         WalkParams P = R.P;
         P.n_photons = bt.second; P.photon_offset = offset;
-        if (bt.first == 1) P.grid = c->d_grid1.p;      // (the log's overflow path adds to the lane's grid)
+        if (bt.first >= 1) P.grid = c->d_gridx[bt.first - 1].p;      // (the log's overflow path adds to the lane's grid)
         P.head = (unsigned long long*)ln.head.p;
         P.log_idx = (uint32_t*)ln.log_idx.p; P.log_val = ln.log_val.p; P.log_fill = (uint32_t*)ln.log_fill.p;
         P.log_next = meta + LM_NEXT; P.log_overflow = meta + LM_OVERFLOW; P.log_cap_chunks = plan.cap_chunks[bt.first];
@@ -515,7 +522,7 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         L.itab = (uint32_t*)ln.itab.p;
         L.meta = meta; L.job = (unsigned long long*)c->d_job.p; L.cap_chunks = P.log_cap_chunks;
         L.n_tiles = G.n_tiles; L.bits2 = G.bits2;
-        L.grid = bt.first == 1 ? c->d_grid1.p : c->d_grid.p; L.n_vox = c->n_vox(); L.tally = c->tally;
+        L.grid = bt.first >= 1 ? c->d_gridx[bt.first - 1].p : c->d_grid.p; L.n_vox = c->n_vox(); L.tally = c->tally;
         L.nx = (uint32_t)c->nx; L.ny = (uint32_t)c->ny; L.nz = (uint32_t)c->nz; L.ntx = G.ntx; L.nty = G.nty;
         L.flush_atomic = 0;
 
@@ -539,10 +546,10 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         offset += bt.second;
         (*n_batches)++;
     }
-    if (plan.lanes == 2) {
-        HIP_TRY(c, hipEventRecord(c->lanes[1].ev_done, c->lanes[1].stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->lanes[1].ev_done, 0));
-        HIP_TRY(c, launch_grid_add(c->d_grid.p, c->d_grid1.p, c->tally, c->n_vox(), c->stream));
+    for (int l = 1; l < plan.lanes; l++) {
+        HIP_TRY(c, hipEventRecord(c->lanes[l].ev_done, c->lanes[l].stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->lanes[l].ev_done, 0));
+        HIP_TRY(c, launch_grid_add(c->d_grid.p, c->d_gridx[l - 1].p, c->tally, c->n_vox(), c->stream));
     }
     return LT_OK;
 }
@@ -607,7 +614,7 @@ int lt_create(lt_ctx** out, int device_id)
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->lanes[k].ev_done, hipEventDisableTiming);
+    for (int k = 0; k < kMaxLanes && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->lanes[k].ev_done, hipEventDisableTiming);
     if (e == hipSuccess) e = c->d_job.ensure(2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = c->d_counters.ensure(sizeof(DevCounters));
     if (e == hipSuccess) e = c->d_head.ensure(sizeof(unsigned long long));
@@ -631,9 +638,9 @@ int lt_destroy(lt_ctx* c)
     c->d_scratch_in.release(); c->d_scratch_out.release(); c->d_scratch_aux.release();
     c->d_mats.release(); c->d_lights.release(); c->d_r0.release(); c->d_r1.release(); c->d_lc.release();
     c->d_img.release(); c->d_xy.release(); c->d_vtx.release(); c->d_vcnt.release(); c->d_clear.release();
-    c->d_job.release(); c->d_grid1.release();
-    if (c->lanes[1].stream) (void)hipStreamSynchronize(c->lanes[1].stream);
-    for (int k = 0; k < 2; k++) {
+    c->d_job.release();
+    for (int k = 1; k < kMaxLanes; k++) { c->d_gridx[k - 1].release(); if (c->lanes[k].stream) (void)hipStreamSynchronize(c->lanes[k].stream); }
+    for (int k = 0; k < kMaxLanes; k++) {
         c->lanes[k].release_all();
         for (hipEvent_t ev : c->lanes[k].evs) (void)hipEventDestroy(ev);
         if (c->lanes[k].ev_done) (void)hipEventDestroy(c->lanes[k].ev_done);
@@ -641,7 +648,7 @@ int lt_destroy(lt_ctx* c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->lanes[1].stream) (void)hipStreamDestroy(c->lanes[1].stream);
+    for (int k = 1; k < kMaxLanes; k++) if (c->lanes[k].stream) (void)hipStreamDestroy(c->lanes[k].stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LT_OK;
@@ -873,7 +880,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         LogRun R;
         R.c = c; R.P = P; R.v = v; R.cfg = cfg; R.G = G;
         c->stages_valid = false;
-        c->lanes[0].ev_used = c->lanes[1].ev_used = 0;
+        for (LogLane& ln : c->lanes) ln.ev_used = 0;
         HIP_TRY(c, hipMemsetAsync(c->d_job.p, 0, 2 * sizeof(unsigned long long), c->stream));
         uint64_t done = 0;
         int n_batches = 0;
@@ -895,7 +902,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
             int lanes = choose_lanes(c, n_photons - done);
             LogPlan plan;
             rc = plan_log(c, n_photons - done, lanes, &plan);
-            if (rc == LT_E_NOMEM && lanes == 2) { lanes = 1; rc = plan_log(c, n_photons - done, 1, &plan); }
+            while (rc == LT_E_NOMEM && lanes > 1) { lanes--; rc = plan_log(c, n_photons - done, lanes, &plan); }
             if (rc == LT_E_NOMEM) { use_log = false; rc = LT_OK; }
             else if (rc) return rc;
             else {
@@ -939,7 +946,7 @@ int lt_reserve_log(lt_ctx* c, uint64_t n_photons)
     if (!c->have_grid) return c->fail(LT_E_STATE, "lt_reserve_log: lt_set_grid first");
     BIND(c);
     LogPlan plan;
-    int lanes = c->overlap_mode == 1 ? 1 : ((c->overlap_mode == 2 || (c->blocks_per_cu == 0 && n_photons >= kOverlapMinPhotons)) ? 2 : 1);
+    int lanes = c->overlap_mode == 1 ? 1 : (c->overlap_mode >= 2 ? c->overlap_mode : ((c->blocks_per_cu == 0 && n_photons >= kOverlapMinPhotons) ? kAutoLanes : 1));
     int rc = plan_log(c, n_photons, lanes, &plan);
     if (rc == LT_E_NOMEM) return c->fail(LT_E_NOMEM, "lt_reserve_log: not enough device memory for the deposit log");
     return rc;
@@ -957,9 +964,10 @@ int lt_set_tally_mode(lt_ctx* c, int mode, uint64_t log_bytes)
 int lt_set_overlap(lt_ctx* c, int lanes)
 {
     CHECK_CTX(c);
-    if (lanes < 0 || lanes > 2) return c->fail(LT_E_INVALID, "lt_set_overlap: 0 (auto), 1 or 2");
+    if (lanes < 0 || lanes > kMaxLanes) return c->fail(LT_E_INVALID, "lt_set_overlap: 0 (auto), 1, 2 or 3");
     c->overlap_mode = lanes;
-    c->auto_ms_per_photon[0] = c->auto_ms_per_photon[1] = 0.0; c->auto_pending = -1;
+    for (double& a : c->auto_ms_per_photon) a = 0.0;
+    c->auto_pending = -1;
     return LT_OK;
 }
 
@@ -993,7 +1001,7 @@ int lt_last_log_stages(lt_ctx* c, double ms_out[4], uint64_t* records, uint64_t*
     HIP_TRY(c, hipEventSynchronize(c->ev1));
     { int rc3 = collect_log_stats(c); if (rc3) return rc3; }
     for (int k = 0; k < 4; k++) ms_out[k] = 0.0;
-    for (int l = 0; l < 2; l++) {
+    for (int l = 0; l < kMaxLanes; l++) {
         const LogLane& ln = c->lanes[l];
         for (size_t b = 0; b + 5 <= ln.ev_used; b += 5) {
             float f;

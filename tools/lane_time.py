@@ -17,7 +17,7 @@ ctx = lt.Context(0)
 for name in (list(cases) if which == "all" else which.split(",")):
     prob, n, dtype, f32 = cases[name]
     prob.apply(ctx, dtype); ctx.set_tally_mode("log")
-    for lanes in (1, 2):
+    for lanes in (1, 2, 3):
         ctx.set_overlap(lanes)
         best, st_best = 1e9, None
         for r in range(reps + 1):
