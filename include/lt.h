@@ -195,6 +195,12 @@ int lt_last_log_stages(lt_ctx* ctx, double ms_out[4], uint64_t* records, uint64_
 /* bookkeeping of the last log-mode lt_launch (blocks until it has finished): records written to the
  * deposit log, records that found it full and went to the grid as atomics, batches, lanes used */
 int lt_last_log_info(lt_ctx* ctx, uint64_t* records, uint64_t* overflow_records, uint64_t* batches, int* lanes);
+/* grids of more than 1024 tiles (a tile = 32 x 32 x 16 voxels) take two partition passes; once a tile histogram of
+ * the scene is known (the pilot batch), the tiles that hold most records ("hot") leave the first pass in their final
+ * form and only the rest goes through the second.  Reports, for the last log-mode lt_launch (blocking): how many tiles
+ * were hot (0: plain two-pass or one-pass form) and the record count of the pilot histogram that made a tile hot.
+ * LT_LOG_HOT=<n> in the environment caps the number of hot tiles (0 switches the form off). */
+int lt_last_log_hot_tiles(lt_ctx* ctx, uint32_t* hot_tiles, uint32_t* threshold);
 
 /* ---- readback ---------------------------------------------------------- */
 /* blocking D2H of the raw tally ([nz][ny][nx], dtype as set) */

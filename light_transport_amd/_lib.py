@@ -28,7 +28,7 @@ SYMBOLS = [
     "lt_grid_device_ptr", "lt_counters_device_ptr", "lt_stream", "lt_reduce_grid", "lt_intersect_rays",
     "lt_triangle_intersect", "lt_intersect_bounds", "lt_eval", "lt_rng_raw", "lt_device_info",
     "lt_set_surface_materials", "lt_set_lights", "lt_render_surface", "lt_set_vertex_capture", "lt_read_vertices",
-    "lt_set_tally_mode", "lt_last_log_stages", "lt_reserve_log", "lt_render_surface_old", "lt_set_overlap",
+    "lt_set_tally_mode", "lt_last_log_stages", "lt_reserve_log", "lt_render_surface_old", "lt_set_overlap", "lt_last_log_hot_tiles",
     "lt_last_log_info",
 ]
 
@@ -240,6 +240,12 @@ class Context:
         if lib().lt_last_log_info(self._h, C.byref(rec), C.byref(ovf), C.byref(bat), C.byref(lanes)) != 0:
             return None
         return dict(records=rec.value, overflow_records=ovf.value, batches=bat.value, lanes=lanes.value)
+
+    def last_log_hot_tiles(self):
+        """(hot tiles, pilot-count threshold) of the last log-mode launch: (0, 0) unless the hot-tile two-pass form ran."""
+        h, t = C.c_uint32(), C.c_uint32()
+        self._ck(lib().lt_last_log_hot_tiles(self._h, C.byref(h), C.byref(t)), "lt_last_log_hot_tiles")
+        return h.value, t.value
 
     def reserve_log(self, n_photons):
         self._ck(lib().lt_reserve_log(self._h, C.c_uint64(int(n_photons))), "lt_reserve_log")

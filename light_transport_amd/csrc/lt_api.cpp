@@ -59,14 +59,14 @@ struct LogLane {
     hipEvent_t ev_done = nullptr;          // end of the lane's last batch
     std::vector<hipEvent_t> evs;           // 5 per batch of the last launch: walk start / end, scan end, partition end, reduce end
     size_t ev_used = 0;
-    DevBuf log_idx, log_val, tmp_idx, tmp_val, log_fill, meta, hist1, hist, bin_base, bin_cnt, tile_base, tile_cnt, cursor1,
+    DevBuf log_idx, log_val, tmp_idx, tmp_val, log_fill, meta, hist1, hist_unused, hist, bin_base, bin_cnt, tile_base, tile_cnt, cursor1,
         cursor2, items2, items_c, items_r, itab, head;
     size_t alloc_records = 0;              // capacity of the log buffers currently allocated (without the slack)
     int alloc_elem = 0;
     void release_log() { log_idx.release(); log_val.release(); tmp_idx.release(); tmp_val.release(); log_fill.release(); alloc_records = 0; }
     void release_all()
     {
-        release_log(); meta.release(); hist1.release(); hist.release(); bin_base.release(); bin_cnt.release(); tile_base.release();
+        release_log(); meta.release(); hist1.release(); hist_unused.release(); hist.release(); bin_base.release(); bin_cnt.release(); tile_base.release();
         tile_cnt.release(); cursor1.release(); itab.release();
         cursor2.release(); items2.release(); items_c.release(); items_r.release(); head.release();
     }
@@ -118,6 +118,10 @@ struct lt_ctx {
     double corg[3] = {0, 0, 0}, ccell[3] = {1, 1, 1};
     bool have_clear = false;
     LogLane lanes[kMaxLanes];
+    // hot-tile form of the two-pass partition (LogReduceParams::dmap): the map is made once per scene from the tile
+    // counts a batch on lane 0 left behind (normally the pilot batch) and shared by every lane
+    DevBuf d_dmap, d_dmeta;
+    bool dmap_valid = false, tile_cnt_ready = false, last_hot = false;
     bool tables_dirty = true;
     bool timed = false;
 
@@ -138,7 +142,7 @@ struct lt_ctx {
     }
     size_t grid_elem() const { return tally == LT_TALLY_F32 ? 4 : 8; }
     size_t n_vox() const { return (size_t)nx * (size_t)ny * (size_t)nz; }
-    void scene_changed() { rec_per_photon = 0.0; for (double& a : auto_ms_per_photon) a = 0.0; auto_pending = -1; }
+    void scene_changed() { rec_per_photon = 0.0; for (double& a : auto_ms_per_photon) a = 0.0; auto_pending = -1; dmap_valid = tile_cnt_ready = false; }
 };
 
 #define CHECK_CTX(c) do { if (!(c)) return LT_E_INVALID; } while (0)
@@ -356,19 +360,22 @@ hipError_t ensure_lane(lt_ctx* c, LogLane& ln, size_t want, size_t limit, const 
         if ((e = ln.itab.ensure((grown / log_part_item() + 1024 + 16) * 16)) != hipSuccess) return e;   // pass-2 item descriptors
         ln.alloc_records = grown;
     }
-    const size_t nt = G.n_tiles, n_hist = G.bits2 ? G.nb1 : G.n_tiles;     // bins of the first partition pass
+    // digits of the first partition pass: the tiles (one pass), the level-1 bins (two passes; with hot tiles in front
+    // of them up to log_max_digits())
+    const size_t nt = G.n_tiles, nd = G.bits2 ? (size_t)log_max_digits() : G.n_tiles;
     if ((e = ln.meta.ensure(LM_WORDS * 4)) != hipSuccess) return e;
     if ((e = ln.head.ensure(sizeof(unsigned long long))) != hipSuccess) return e;
     if ((e = ln.hist.ensure(nt * kLogGroups * 4)) != hipSuccess) return e;
-    if ((e = ln.hist1.ensure((size_t)G.nb1 * kLogGroups * 4)) != hipSuccess) return e;
-    if ((e = ln.bin_base.ensure(((size_t)G.nb1 + 1) * 4)) != hipSuccess) return e;
-    if ((e = ln.bin_cnt.ensure(((size_t)G.nb1 + 1) * 4)) != hipSuccess) return e;
+    if ((e = ln.hist1.ensure(nd * kLogGroups * 4)) != hipSuccess) return e;
+    if (G.bits2 && (e = ln.hist_unused.ensure(nd * kLogGroups * 4)) != hipSuccess) return e;
+    if ((e = ln.bin_base.ensure((nd + 1) * 4)) != hipSuccess) return e;
+    if ((e = ln.bin_cnt.ensure((nd + 1) * 4)) != hipSuccess) return e;
     if ((e = ln.tile_base.ensure((nt + 1) * 4)) != hipSuccess) return e;
     if ((e = ln.tile_cnt.ensure((nt + 1) * 4)) != hipSuccess) return e;
-    if ((e = ln.cursor1.ensure(n_hist * kLogGroups * 4)) != hipSuccess) return e;
+    if ((e = ln.cursor1.ensure(nd * kLogGroups * 4)) != hipSuccess) return e;
     if ((e = ln.cursor2.ensure(nt * kLogGroups2 * 4)) != hipSuccess) return e;
-    if ((e = ln.items2.ensure(((size_t)G.nb1 + 1) * 4)) != hipSuccess) return e;
-    if ((e = ln.items_c.ensure(((size_t)G.nb1 + 1) * 4)) != hipSuccess) return e;
+    if ((e = ln.items2.ensure((nd + 1) * 4)) != hipSuccess) return e;
+    if ((e = ln.items_c.ensure((nd + 1) * 4)) != hipSuccess) return e;
     return ln.items_r.ensure((nt + 1) * 4);
 }
 
@@ -471,6 +478,9 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
 {
     lt_ctx* c = R.c;
     const LogGeom& G = R.G;
+    // hot-tile form (two-pass grids with a map, see lt_launch): k_log_count1 counts the digits of pass 1; the walk's
+    // level-1 histogram goes to a buffer nobody reads (the walk kernels stay as they are)
+    const bool hot = G.bits2 != 0 && c->dmap_valid;
     const uint32_t n_hist = G.bits2 ? G.nb1 : G.n_tiles;
     LaunchCfg cfg = R.cfg;
     cfg.lds_bytes = walk_lds_bytes(R.v, R.P.n_media, R.P.n_layers, R.P.n_tris, R.P.n_nodes, n_hist);
@@ -504,7 +514,7 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         P.head = (unsigned long long*)ln.head.p;
         P.log_idx = (uint32_t*)ln.log_idx.p; P.log_val = ln.log_val.p; P.log_fill = (uint32_t*)ln.log_fill.p;
         P.log_next = meta + LM_NEXT; P.log_overflow = meta + LM_OVERFLOW; P.log_cap_chunks = plan.cap_chunks[bt.first];
-        P.log_hist = (uint32_t*)(G.bits2 ? ln.hist1.p : ln.hist.p); P.log_n_hist = n_hist; P.log_hist_shift = kTileShift + G.bits2;
+        P.log_hist = (uint32_t*)(hot ? ln.hist_unused.p : (G.bits2 ? ln.hist1.p : ln.hist.p)); P.log_n_hist = n_hist; P.log_hist_shift = kTileShift + G.bits2;
         P.log_ntx = G.ntx; P.log_nty = G.nty;
         const unsigned long long want = (bt.second + (unsigned long long)cfg.threads - 1) / (unsigned long long)cfg.threads;
         cfg.blocks = (int)(want < cap ? want : cap);
@@ -525,15 +535,17 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         L.grid = bt.first >= 1 ? c->d_gridx[bt.first - 1].p : c->d_grid.p; L.n_vox = c->n_vox(); L.tally = c->tally;
         L.nx = (uint32_t)c->nx; L.ny = (uint32_t)c->ny; L.nz = (uint32_t)c->nz; L.ntx = G.ntx; L.nty = G.nty;
         L.flush_atomic = 0;
+        if (hot) { L.dmap = (const uint16_t*)c->d_dmap.p; L.dmeta = (const uint32_t*)c->d_dmeta.p; }
 
         HIP_TRY(c, hipMemsetAsync(ln.head.p, 0, sizeof(unsigned long long), s));
         HIP_TRY(c, hipMemsetAsync(meta, 0, LM_WORDS * 4, s));
         HIP_TRY(c, hipMemsetAsync(ln.hist.p, 0, (size_t)G.n_tiles * (G.bits2 ? kLogGroups2 : kLogGroups) * 4, s));
         HIP_TRY(c, hipMemsetAsync(ln.log_fill.p, 0, (size_t)P.log_cap_chunks * 4, s));   // unclaimed chunk indices read as empty
-        if (G.bits2) HIP_TRY(c, hipMemsetAsync(ln.hist1.p, 0, (size_t)G.nb1 * kLogGroups * 4, s));
+        if (G.bits2) HIP_TRY(c, hipMemsetAsync(ln.hist1.p, 0, (size_t)(hot ? log_max_digits() : G.nb1) * kLogGroups * 4, s));
         HIP_TRY(c, lane_event(ln, s));
         HIP_TRY(c, launch_walk(P, R.v, cfg, s));
         HIP_TRY(c, lane_event(ln, s));
+        if (hot) HIP_TRY(c, launch_log_count1(L, s));
         HIP_TRY(c, G.bits2 ? launch_log_scan_bins(L, s) : launch_log_scan_tiles(L, s));
         HIP_TRY(c, lane_event(ln, s));
         HIP_TRY(c, launch_log_part1(L, s));
@@ -543,6 +555,7 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         HIP_TRY(c, lane_event(ln, s));
         HIP_TRY(c, launch_log_reduce(Lr, s));
         HIP_TRY(c, lane_event(ln, s));
+        if (bt.first == 0 && G.bits2) c->tile_cnt_ready = true;      // lane 0's tile_cnt: this scene's records per tile
         offset += bt.second;
         (*n_batches)++;
     }
@@ -638,7 +651,7 @@ int lt_destroy(lt_ctx* c)
     c->d_scratch_in.release(); c->d_scratch_out.release(); c->d_scratch_aux.release();
     c->d_mats.release(); c->d_lights.release(); c->d_r0.release(); c->d_r1.release(); c->d_lc.release();
     c->d_img.release(); c->d_xy.release(); c->d_vtx.release(); c->d_vcnt.release(); c->d_clear.release();
-    c->d_job.release();
+    c->d_job.release(); c->d_dmap.release(); c->d_dmeta.release();
     for (int k = 1; k < kMaxLanes; k++) { c->d_gridx[k - 1].release(); if (c->lanes[k].stream) (void)hipStreamSynchronize(c->lanes[k].stream); }
     for (int k = 0; k < kMaxLanes; k++) {
         c->lanes[k].release_all();
@@ -898,6 +911,19 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
                 done = kPilotPhotons;
             }
         }
+        if (use_log && G.bits2 && !c->dmap_valid && c->tile_cnt_ready && G.n_tiles <= kMaxHotTiles && G.nb1 < log_max_digits()) {
+            // two-pass grid with a measured tile histogram (the pilot's, or an earlier small launch's): make the
+            // hot-tile map for this scene.  LT_LOG_HOT caps the number of hot tiles (0: plain two-pass form).
+            uint32_t max_hot = log_max_digits() - G.nb1;
+            if (const char* e = std::getenv("LT_LOG_HOT")) { const long v_ = std::atol(e); if (v_ >= 0 && (uint32_t)v_ < max_hot) max_hot = (uint32_t)v_; }
+            if (max_hot > 0) {
+                HIP_TRY(c, c->d_dmap.ensure(((size_t)G.n_tiles + 2) * sizeof(uint16_t)));
+                HIP_TRY(c, c->d_dmeta.ensure(4 * sizeof(uint32_t)));
+                HIP_TRY(c, launch_log_plan((const uint32_t*)c->lanes[0].tile_cnt.p, G.n_tiles, G.bits2, max_hot, (uint16_t*)c->d_dmap.p,
+                                           (uint32_t*)c->d_dmeta.p, c->stream));
+                c->dmap_valid = true;
+            }
+        }
         if (use_log) {
             int lanes = choose_lanes(c, n_photons - done);
             LogPlan plan;
@@ -910,6 +936,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
                 if ((rc = run_log_plan(R, plan, photon_offset + done, &n_batches))) return rc;
                 HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
                 c->stages_valid = true; c->last_batches = (uint64_t)n_batches; c->last_lanes = plan.lanes;
+                c->last_hot = G.bits2 != 0 && c->dmap_valid;
                 c->log_stats_pending = true; c->pending_photons = n_photons;   // the job counters hold the pilot's records too
                 if (c->auto_pending >= 0 && done > 0) c->auto_pending = -1;     // (first launch of a scene: not a clean measurement)
                 c->timed = true;
@@ -958,6 +985,21 @@ int lt_set_tally_mode(lt_ctx* c, int mode, uint64_t log_bytes)
     if (mode < 0 || mode > 2) return c->fail(LT_E_INVALID, "lt_set_tally_mode: mode must be LT_MODE_ATOMIC, LT_MODE_LOG or LT_MODE_AUTO");
     c->tally_mode = mode;
     c->log_budget = log_bytes ? (size_t)log_bytes : c->default_log_budget;
+    return LT_OK;
+}
+
+int lt_last_log_hot_tiles(lt_ctx* c, uint32_t* hot_tiles, uint32_t* threshold)
+{
+    CHECK_CTX(c);
+    if (!c->stages_valid) return c->fail(LT_E_STATE, "lt_last_log_hot_tiles: the last launch did not use the deposit log");
+    BIND(c);
+    uint32_t m[2] = {0, 0};
+    if (c->last_hot) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpy(m, c->d_dmeta.p, sizeof m, hipMemcpyDeviceToHost));
+    }
+    if (hot_tiles) *hot_tiles = m[0];
+    if (threshold) *threshold = m[1];
     return LT_OK;
 }
 

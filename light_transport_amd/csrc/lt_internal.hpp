@@ -160,7 +160,7 @@ enum { LM_NEXT = 0,        // [kLogGroups] chunks the walk claimed per group (ma
 static_assert(kLogGroups == 16, "LM_NEXT holds one counter per group");
 // tile / bin regions start at multiples of these record counts so that the wide (16-byte) loads of the next pass are
 // aligned; the gaps are never read (a region's length comes from the histogram), the buffers carry the slack
-constexpr uint32_t kTileAlign = 8, kBinAlign = 4;
+constexpr uint32_t kTileAlign = 8, kBinAlign = 8;     // (a hot tile's bin is read by the reduce: 8 records per 16-byte load)
 
 // log-structured tally pipeline (all on stream s)
 struct LogReduceParams {
@@ -183,10 +183,22 @@ struct LogReduceParams {
     uint32_t n_tiles, bits2;                   // level-2 digit width; level-1 bins = ceil(n_tiles >> bits2); 0 = one pass
     void* grid; size_t n_vox; int tally;
     uint32_t nx, ny, nz, ntx, nty;             // grid shape and tile counts along x, y (tiled record index)
+    // Hot-tile form of the two-pass partition (null / 0: off).  dmap[tile] = digit of pass 1: the H tiles that held the
+    // most records when the map was made ("hot", H = dmeta[0]) have digits 0 .. H-1 of their own and leave pass 1 in
+    // their final form; every other tile shares digit H + (tile >> bits2) with its level-1 bin and goes through pass 2.
+    // Any map gives the same grid; a good one (k_log_plan, from a measured tile histogram) saves the second pass for
+    // most records.  The walk's level-1 histogram is not used in this form: k_log_count1 counts the digits from the log.
+    const uint16_t* dmap; const uint32_t* dmeta;
     int flush_atomic;                          // every tile adds to the grid with atomics (another lane of the same
                                                // launch may be updating it at the same time)
 };
 hipError_t launch_log_scan_bins(const LogReduceParams& L, hipStream_t s);
+hipError_t launch_log_count1(const LogReduceParams& L, hipStream_t s);      // hot-tile form: pass-1 digit histogram from the log
+// hot-tile map from a tile histogram: at most max_hot tiles, the ones with the most records (dmeta[0] = their number)
+hipError_t launch_log_plan(const uint32_t* tile_cnt, uint32_t n_tiles, uint32_t bits2, uint32_t max_hot, uint16_t* dmap,
+                           uint32_t* dmeta, hipStream_t s);
+uint32_t log_max_digits();  // digits one partition pass can tell apart (1024)
+constexpr uint32_t kMaxHotTiles = 8192;    // the map lives in LDS (2 bytes per tile: 16 KiB beside a partition item's 56 KiB, two workgroups per CU)
 hipError_t launch_log_scan_tiles(const LogReduceParams& L, hipStream_t s);
 hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s);
 hipError_t launch_log_part2(const LogReduceParams& L, hipStream_t s);

@@ -85,17 +85,23 @@ __device__ __forceinline__ uint32_t round_up(uint32_t x, uint32_t a) { return (x
 // same-address serialisation of the LDS adds on hot voxels).
 __global__ void __launch_bounds__(kScanThreads) k_log_scan_tiles(const uint32_t* hist, uint32_t G, uint32_t* tile_base,
                                                                 uint32_t* tile_cnt, uint32_t* cursor, uint32_t* items_r,
-                                                                uint32_t* meta, unsigned long long* job, uint32_t n_tiles)
+                                                                uint32_t* meta, unsigned long long* job, uint32_t n_tiles,
+                                                                const uint16_t* dmap, const uint32_t* dmeta,
+                                                                const uint32_t* bin_base, const uint32_t* bin_cnt)
 {
     __shared__ uint32_t s_wave[kScanThreads / 64];
     __shared__ uint32_t s_tot[3];
     const uint32_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
     const uint32_t t0 = threadIdx.x * per < n_tiles ? threadIdx.x * per : n_tiles, t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+    // hot-tile form: a hot tile's records already sit, final, in its own bin of pass 1's output
+    const uint32_t H = dmap ? dmeta[0] : 0u;
     uint32_t cnt = 0, pad = 0;
     for (uint32_t t = t0; t < t1; t++) {
         uint32_t h = 0;
-        for (uint32_t g = 0; g < G; g++) h += hist[t * G + g];
-        tile_cnt[t] = h; cnt += h; pad += round_up(h, kTileAlign);
+        const uint32_t d = dmap ? dmap[t] : 0u;
+        if (d < H) h = bin_cnt[d];
+        else { for (uint32_t g = 0; g < G; g++) h += hist[t * G + g]; pad += round_up(h, kTileAlign); }
+        tile_cnt[t] = h; cnt += h;
     }
     uint32_t base = block_exclusive_scan(pad, s_wave, &s_tot[0]);
     (void)block_exclusive_scan(cnt, s_wave, &s_tot[1]);
@@ -109,10 +115,16 @@ __global__ void __launch_bounds__(kScanThreads) k_log_scan_tiles(const uint32_t*
     uint32_t rbase = block_exclusive_scan(rit, s_wave, &s_tot[2]);
     for (uint32_t t = t0; t < t1; t++) {
         const uint32_t h = tile_cnt[t];
-        tile_base[t] = base; items_r[t] = rbase;
-        uint32_t run = base;
-        for (uint32_t g = 0; g < G; g++) { cursor[t * G + g] = run; run += hist[t * G + g]; }
-        base += round_up(h, kTileAlign); rbase += (h + slice - 1) / slice;
+        const uint32_t d = dmap ? dmap[t] : 0u;
+        items_r[t] = rbase;
+        if (d < H) tile_base[t] = bin_base[d];
+        else {
+            tile_base[t] = base;
+            uint32_t run = base;
+            for (uint32_t g = 0; g < G; g++) { cursor[t * G + g] = run; run += hist[t * G + g]; }
+            base += round_up(h, kTileAlign);
+        }
+        rbase += (h + slice - 1) / slice;
     }
     if (threadIdx.x == 0) {
         tile_base[n_tiles] = s_tot[0]; items_r[n_tiles] = s_tot[2];
@@ -121,28 +133,30 @@ __global__ void __launch_bounds__(kScanThreads) k_log_scan_tiles(const uint32_t*
     }
 }
 
-// Two-pass form, per level-1 bin: where pass 1 puts it (starts padded to kBinAlign), one cursor per group, the prefix
-// of pass-2 work items and of k_log_count2 work items.
+// Two-pass form, per digit of pass 1 (the level-1 bins; in the hot-tile form H hot tiles come first): where pass 1 puts
+// it (starts padded to kBinAlign), one cursor per group, the prefix of pass-2 work items and of k_log_count2 work
+// items (none for a hot tile: it is final after pass 1).
 __global__ void __launch_bounds__(kScanThreads) k_log_scan_bins(const uint32_t* hist1, uint32_t* bin_base, uint32_t* bin_cnt,
                                                                uint32_t* cursor1, uint32_t* items2, uint32_t* items_c,
-                                                               uint32_t* meta, uint32_t nb1)
+                                                               uint32_t* meta, uint32_t nb1, const uint32_t* dmeta)
 {
     __shared__ uint32_t s_wave[kScanThreads / 64];
     __shared__ uint32_t s_tot[3];
+    const uint32_t H = dmeta ? dmeta[0] : 0u, nd = H + nb1;      // <= kScanThreads (k_log_plan bounds H)
     const uint32_t b = threadIdx.x;
     uint32_t h = 0;
-    if (b < nb1) for (uint32_t g = 0; g < kLogGroups; g++) h += hist1[b * kLogGroups + g];
-    const uint32_t it = (h + kPartItem - 1) / kPartItem, ic = (it + kCountGroup - 1) / kCountGroup;
+    if (b < nd) for (uint32_t g = 0; g < kLogGroups; g++) h += hist1[b * kLogGroups + g];
+    const uint32_t it = b < H ? 0u : (h + kPartItem - 1) / kPartItem, ic = (it + kCountGroup - 1) / kCountGroup;
     const uint32_t base = block_exclusive_scan(round_up(h, kBinAlign), s_wave, &s_tot[0]);
     const uint32_t ibase = block_exclusive_scan(it, s_wave, &s_tot[1]);
     const uint32_t cbase = block_exclusive_scan(ic, s_wave, &s_tot[2]);
-    if (b < nb1) {
+    if (b < nd) {
         bin_base[b] = base; bin_cnt[b] = h; items2[b] = ibase; items_c[b] = cbase;
         uint32_t run = base;
         for (uint32_t g = 0; g < kLogGroups; g++) { cursor1[b * kLogGroups + g] = run; run += hist1[b * kLogGroups + g]; }
     }
     if (b == 0) {
-        bin_base[nb1] = s_tot[0]; items2[nb1] = s_tot[1]; items_c[nb1] = s_tot[2];
+        bin_base[nd] = s_tot[0]; items2[nd] = s_tot[1]; items_c[nd] = s_tot[2];
         meta[LM_ITEMS2] = s_tot[1]; meta[LM_ITEMS_C] = s_tot[2];
     }
 }
@@ -157,14 +171,14 @@ __device__ __forceinline__ uint32_t upper_slot(const uint32_t* prefix, uint32_t 
 
 // ---------------------------------------------------------------------------------------------------------
 // Two-pass form: descriptor of every pass-2 work unit (up to kCountGroup x 4096 consecutive records of ONE level-1
-// bin in pass 1's output: where they start, how many, which bin), so that k_log_count2 and pass 2 read one record per
+// bin in pass 1's output: where they start, how many, which pass-1 digit), so that k_log_count2 and pass 2 read one record per
 // unit -- a unit ahead -- instead of searching the bin prefix with dependent loads while 511 lanes wait.
 __global__ void __launch_bounds__(256) k_log_items2(LogReduceParams L)
 {
-    const uint32_t nb1 = (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2;
+    const uint32_t nd = (L.dmap ? L.dmeta[0] : 0u) + ((L.n_tiles + (1u << L.bits2) - 1) >> L.bits2);
     const uint32_t n_units = L.meta[LM_ITEMS_C];
     for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += gridDim.x * blockDim.x) {
-        const uint32_t a = upper_slot(L.items_c, nb1, u);
+        const uint32_t a = upper_slot(L.items_c, nd, u);      // digit of pass 1 (hot tiles have no units)
         const uint32_t done = (u - L.items_c[a]) * (kCountGroup * kPartItem), left = L.bin_cnt[a] - done;
         reinterpret_cast<uint4*>(L.itab)[u] =
             make_uint4(L.bin_base[a] + done, left < kCountGroup * kPartItem ? left : kCountGroup * kPartItem, a, 0u);
@@ -196,7 +210,7 @@ __device__ __forceinline__ uint32_t claimed_chunks(const LogReduceParams& L)
 #ifndef LT_PART_WAVES
 #define LT_PART_WAVES 8
 #endif
-template <typename TV, int PASS>
+template <typename TV, int PASS, bool HOT>
 __global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogReduceParams L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -204,13 +218,21 @@ __global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogRed
     uint32_t* s_key = reinterpret_cast<uint32_t*>(s_dyn + (size_t)kPartItem * sizeof(TV));      // [kPartItem]
     uint32_t* s_a = s_key + kPartItem;        // [kMaxBins + 2] digit counts, then exclusive offsets
     uint32_t* s_b = s_a + kMaxBins + 2;       // [kMaxBins]     global base of the digit's run minus its offset
+    const uint16_t* s_dmap = reinterpret_cast<const uint16_t*>(s_b + kMaxBins);   // [n_tiles], HOT only
     __shared__ uint32_t s_wsum[kPartThreads / 64];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nb1 = L.bits2 ? (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2 : L.n_tiles;
     const uint32_t mask2 = (1u << L.bits2) - 1;
-    const uint32_t nb = PASS == 1 ? nb1 : (1u << L.bits2);
+    const uint32_t H = L.dmap ? L.dmeta[0] : 0u;          // hot tiles: pass-1 digits 0 .. H-1, final after pass 1
+    const uint32_t nb = PASS == 1 ? H + nb1 : (1u << L.bits2);
     const bool final_pass = PASS == 2 || L.bits2 == 0;
+    if (HOT) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(s_b + kMaxBins);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(L.dmap);      // (the map is padded to a whole word)
+        for (uint32_t i = threadIdx.x; i < (L.n_tiles + 1) / 2; i += kPartThreads) w[i] = src[i];
+        __syncthreads();
+    }
     // the amount of work lives in device memory (chunks the walk claimed / units the scan derived), so the host never
     // has to read anything back between the kernels of a batch
     const uint32_t n_units = PASS == 1 ? claimed_chunks(L) : L.meta[LM_ITEMS_C];
@@ -219,7 +241,7 @@ __global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogRed
     const TV* in_val = reinterpret_cast<const TV*>(PASS == 1 ? L.log_val : L.tmp_val);
     uint32_t* out_idx = PASS == 1 ? L.tmp_idx : const_cast<uint32_t*>(L.log_idx);
     TV* out_val = reinterpret_cast<TV*>(PASS == 1 ? L.tmp_val : const_cast<void*>(L.log_val));
-    auto digit = [&](uint32_t k_) { const uint32_t t_ = tile_of(k_); return PASS == 1 ? (t_ >> L.bits2) : (t_ & mask2); };
+    auto digit = [&](uint32_t k_) -> uint32_t { const uint32_t t_ = tile_of(k_); return PASS == 1 ? (HOT ? (uint32_t)s_dmap[t_] : (t_ >> L.bits2)) : (t_ & mask2); };
 
     // unit descriptor (start, records, level-1 bin): pass 1 -- a chunk and its fill; pass 2 -- k_log_items2's table
     auto describe = [&](uint32_t u) -> uint4 {
@@ -263,7 +285,7 @@ __global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogRed
     uint32_t* cursor;
     uint32_t cstride;
     if (PASS == 1) { cursor = L.cursor1 + (unit & (kLogGroups - 1)); cstride = kLogGroups; }        // the cursors of the chunk's group
-    else { cursor = L.cursor2 + ((size_t)(ds.z << L.bits2) * kLogGroups2 + (unit & (kLogGroups2 - 1))); cstride = kLogGroups2; }
+    else { cursor = L.cursor2 + ((size_t)((ds.z - H) << L.bits2) * kLogGroups2 + (unit & (kLogGroups2 - 1))); cstride = kLogGroups2; }
     if (n != 0) {
     for (uint32_t d = threadIdx.x; d < nb + 2; d += kPartThreads) s_a[d] = 0;
     __syncthreads();
@@ -325,10 +347,12 @@ __global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogRed
         const uint32_t p = threadIdx.x + (uint32_t)i * kPartThreads;
         if (p < n) {
             const uint32_t kk = s_key[p];
-            const uint32_t dst = s_b[digit(kk)] + p;
+            const uint32_t dg = digit(kk);
+            const uint32_t dst = s_b[dg] + p;
             // the last pass leaves a tile's records together, so only the 14-bit position inside the tile is kept:
-            // 2 bytes instead of 4 written here and read by the reduce
-            if (final_pass) reinterpret_cast<uint16_t*>(out_idx)[dst] = (uint16_t)(kk & (kTileSize - 1));
+            // 2 bytes instead of 4 written here and read by the reduce.  (Hot tiles come first in pass 1's output, so
+            // their 2-byte positions [0, 2 D) never meet the 4-byte indices of the bins behind them [4 D, ...).)
+            if (final_pass || (HOT && dg < H)) reinterpret_cast<uint16_t*>(out_idx)[dst] = (uint16_t)(kk & (kTileSize - 1));
             else out_idx[dst] = kk;
             out_val[dst] = s_val[p];
         }
@@ -353,12 +377,13 @@ __global__ void __launch_bounds__(kPartThreads) k_log_count2(LogReduceParams L)
     __shared__ uint32_t s_cnt[1u << kMaxBits2];
     const uint32_t mask2 = (1u << L.bits2) - 1;
     const uint32_t n_units = L.meta[LM_ITEMS_C];
+    const uint32_t H = L.dmap ? L.dmeta[0] : 0u;
     const int lane = threadIdx.x & 63;
   for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
     const uint4 ds = reinterpret_cast<const uint4*>(L.itab)[unit];
     if (threadIdx.x < (1u << kMaxBits2)) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t lo = ds.x, n = ds.y, bin = ds.z;
+    const uint32_t lo = ds.x, n = ds.y, bin = ds.z - H;
     for (uint32_t k = threadIdx.x * 4; k < n; k += kPartThreads * 4) {    // lo is a multiple of 4: aligned 16-byte loads
         const uint4 q = *reinterpret_cast<const uint4*>(L.tmp_idx + lo + k);
         const uint32_t kk[4] = {q.x, q.y, q.z, q.w};
@@ -388,6 +413,72 @@ __global__ void __launch_bounds__(kPartThreads) k_log_count2(LogReduceParams L)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Hot-tile form: records per pass-1 digit and group, counted from the log (indices only: 4 of a record's 12 bytes).
+// A workgroup serves the chunks of ONE group (the grid is a multiple of kLogGroups) and flushes its LDS histogram once.
+__global__ void __launch_bounds__(kPartThreads) k_log_count1(LogReduceParams L)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_dyn);                       // [kMaxBins]
+    uint32_t* s_map32 = s_cnt + kMaxBins;
+    const uint16_t* s_dmap = reinterpret_cast<const uint16_t*>(s_map32);       // [n_tiles]
+    const uint32_t nb1 = (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2;
+    const uint32_t nd = L.dmeta[0] + nb1;
+    const uint32_t n_units = claimed_chunks(L);
+    for (uint32_t d = threadIdx.x; d < (uint32_t)kMaxBins; d += kPartThreads) s_cnt[d] = 0;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(L.dmap);
+    for (uint32_t i = threadIdx.x; i < (L.n_tiles + 1) / 2; i += kPartThreads) s_map32[i] = src[i];
+    __syncthreads();
+    for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const uint32_t lo = unit * kLogChunk, n = L.log_fill[unit];
+        for (uint32_t k = threadIdx.x * 4; k < n; k += kPartThreads * 4) {
+            const uint4 q = *reinterpret_cast<const uint4*>(L.log_idx + lo + k);
+            const uint32_t kk[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (k + j < n) atomicAdd(&s_cnt[s_dmap[tile_of(kk[j])]], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < nd; d += kPartThreads)
+        if (s_cnt[d]) __hip_atomic_fetch_add(&L.hist1[d * kLogGroups + (blockIdx.x & (kLogGroups - 1))], s_cnt[d], __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Hot-tile map from a tile histogram (the tile counts of an earlier batch of the same scene -- normally the pilot
+// batch): the tiles with >= tau records are hot, tau the smallest threshold that leaves at most max_hot of them.
+// One workgroup; the histogram is a few thousand words.
+__global__ void __launch_bounds__(kScanThreads) k_log_plan(const uint32_t* cnt, uint32_t n_tiles, uint32_t bits2, uint32_t max_hot,
+                                                          uint16_t* dmap, uint32_t* dmeta)
+{
+    __shared__ uint32_t s_wave[kScanThreads / 64];
+    __shared__ uint32_t s_tot, s_n;
+    const uint32_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
+    const uint32_t t0 = threadIdx.x * per < n_tiles ? threadIdx.x * per : n_tiles, t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+    uint32_t a = 1u, b = 0xffffffffu;         // invariant: #{cnt >= b} <= max_hot
+    while (a < b) {
+        const uint32_t m = a + ((b - a) >> 1);
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        uint32_t mine = 0;
+        for (uint32_t t = t0; t < t1; t++) mine += cnt[t] >= m ? 1u : 0u;
+        if (mine) atomicAdd(&s_n, mine);
+        __syncthreads();
+        const uint32_t n = s_n;
+        __syncthreads();
+        if (n <= max_hot) b = m; else a = m + 1u;
+    }
+    const uint32_t tau = a;
+    uint32_t mine = 0;
+    for (uint32_t t = t0; t < t1; t++) mine += cnt[t] >= tau ? 1u : 0u;
+    uint32_t rank = block_exclusive_scan(mine, s_wave, &s_tot);
+    const uint32_t H = s_tot;
+    for (uint32_t t = t0; t < t1; t++) {
+        if (cnt[t] >= tau) dmap[t] = (uint16_t)rank++;
+        else dmap[t] = (uint16_t)(H + (t >> bits2));
+    }
+    if (threadIdx.x == 0) { dmeta[0] = H; dmeta[1] = tau; if (n_tiles & 1u) dmap[n_tiles] = 0; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 constexpr int kReduceThreads = 512;
 #ifndef LT_REDUCE_WAVES
 #define LT_REDUCE_WAVES 8     /* <= 64 VGPRs: the reduce workgroup (2 waves per SIMD) fits the 128 registers three walk waves leave */
@@ -409,7 +500,7 @@ __global__ void __launch_bounds__(kReduceThreads, LT_REDUCE_WAVES) k_log_reduce(
     typedef typename AccT<TV>::type AT;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     AT* s_tile = reinterpret_cast<AT*>(s_raw);
-    __shared__ uint32_t s_item[2][5];     // [tile, lo, hi, slices of the tile, item] of the current and the next work item
+    __shared__ uint32_t s_item[2][6];     // [tile, lo, hi, slices of the tile, item, hot] of the current and the next work item
     const uint32_t n_items = L.meta[LM_ITEMS_R], slice = L.meta[LM_SLICE];
     // work items differ in size (a slice holds up to `slice` records, most tiles far fewer): they are pulled from a
     // device counter (a few thousand per launch).  Lane 0 claims and describes the NEXT item while the workgroup adds
@@ -422,6 +513,7 @@ __global__ void __launch_bounds__(kReduceThreads, LT_REDUCE_WAVES) k_log_reduce(
             const uint32_t lo = L.tile_base[a] + (item - L.items_r[a]) * slice, end = L.tile_base[a] + L.tile_cnt[a];
             out[0] = a; out[1] = lo; out[2] = end - lo < slice ? end : lo + slice;
             out[3] = L.items_r[a + 1] - L.items_r[a];
+            out[5] = L.dmap && L.dmap[a] < L.dmeta[0];      // hot tile: final in pass 1's output (the tmp buffers)
         }
     };
     if (threadIdx.x == 0) claim(s_item[0]);
@@ -432,8 +524,9 @@ __global__ void __launch_bounds__(kReduceThreads, LT_REDUCE_WAVES) k_log_reduce(
     if (threadIdx.x == 0) claim(s_item[cur ^ 1]);
     const uint32_t t = s_item[cur][0], lo = s_item[cur][1], hi = s_item[cur][2];
     const bool shared_tile = L.flush_atomic || s_item[cur][3] > 1;
-    const uint16_t* idx = reinterpret_cast<const uint16_t*>(L.log_idx);   // in-tile positions, see k_log_part's last pass
-    const TV* val = reinterpret_cast<const TV*>(L.log_val);
+    const bool hot = __builtin_amdgcn_readfirstlane((int)s_item[cur][5]) != 0;     // (scalar: the buffer choice costs no vector register)
+    const uint16_t* idx = reinterpret_cast<const uint16_t*>(hot ? L.tmp_idx : L.log_idx);   // in-tile positions, see k_log_part's last pass
+    const TV* val = reinterpret_cast<const TV*>(hot ? L.tmp_val : L.log_val);
     // `lo` is a multiple of 8 records (tile starts are padded, slices are multiples of 8192): a lane takes 8
     // consecutive records with one 16-byte load of positions and 2 (f32) / 4 (f64, u64) 16-byte loads of values, and
     // keeps two such groups in flight -- the tile pins the workgroup at 8 waves per CU, so the memory-level
@@ -474,12 +567,14 @@ __global__ void __launch_bounds__(kReduceThreads, LT_REDUCE_WAVES) k_log_reduce(
 }  // namespace
 
 uint32_t log_part_item() { return kPartItem; }
+uint32_t log_max_digits() { return (uint32_t)kMaxBins; }
 
 hipError_t launch_log_scan_tiles(const LogReduceParams& L, hipStream_t s)
 {
     // one-pass form: the only partition pass is the final one and runs on cursor1
     hipLaunchKernelGGL(k_log_scan_tiles, dim3(1), dim3(kScanThreads), 0, s, L.hist, L.bits2 ? kLogGroups2 : kLogGroups, L.tile_base, L.tile_cnt,
-                       L.bits2 ? L.cursor2 : L.cursor1, L.items_r, L.meta, L.job, L.n_tiles);
+                       L.bits2 ? L.cursor2 : L.cursor1, L.items_r, L.meta, L.job, L.n_tiles, L.bits2 ? L.dmap : nullptr, L.dmeta,
+                       L.bin_base, L.bin_cnt);
     return hipGetLastError();
 }
 
@@ -488,7 +583,16 @@ hipError_t launch_log_scan_bins(const LogReduceParams& L, hipStream_t s)
     const uint32_t nb1 = (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2;
     if (L.bits2 == 0 || L.bits2 > kMaxBits2 || nb1 > (uint32_t)kMaxBins) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_log_scan_bins, dim3(1), dim3(kScanThreads), 0, s, L.hist1, L.bin_base, L.bin_cnt, L.cursor1, L.items2,
-                       L.items_c, L.meta, nb1);
+                       L.items_c, L.meta, nb1, L.dmap ? L.dmeta : nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_log_plan(const uint32_t* tile_cnt, uint32_t n_tiles, uint32_t bits2, uint32_t max_hot, uint16_t* dmap,
+                           uint32_t* dmeta, hipStream_t s)
+{
+    const uint32_t nb1 = (n_tiles + (1u << bits2) - 1) >> bits2;
+    if (bits2 == 0 || n_tiles > kMaxHotTiles || nb1 + max_hot > (uint32_t)kMaxBins) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_log_plan, dim3(1), dim3(kScanThreads), 0, s, tile_cnt, n_tiles, bits2, max_hot, dmap, dmeta);
     return hipGetLastError();
 }
 
@@ -507,25 +611,47 @@ static unsigned persistent_blocks(std::atomic<unsigned>& cache, const void* fn, 
     return b;
 }
 
-template <typename TV, int PASS> static hipError_t launch_part_t(const LogReduceParams& L, hipStream_t s)
+// the hot-tile map of k_log_part<.., 1, true> / k_log_count1 in LDS: one size for every grid, so that the occupancy
+// (and the cached persistent grid) does not depend on the scene
+constexpr size_t kMapLds = (size_t)kMaxHotTiles * sizeof(uint16_t) + 4;
+
+template <typename TV, int PASS, bool HOT> static hipError_t launch_part_t(const LogReduceParams& L, hipStream_t s)
 {
-    const size_t lds = (size_t)kPartItem * (sizeof(TV) + sizeof(uint32_t)) + (size_t)(2 * kMaxBins + 2) * sizeof(uint32_t);
-    const void* fn = reinterpret_cast<const void*>(&k_log_part<TV, PASS>);
+    const size_t lds = (size_t)kPartItem * (sizeof(TV) + sizeof(uint32_t)) + (size_t)(2 * kMaxBins + 2) * sizeof(uint32_t) +
+                       (HOT ? kMapLds : 0);
+    const void* fn = reinterpret_cast<const void*>(&k_log_part<TV, PASS, HOT>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     static std::atomic<unsigned> blocks{0};   // per instantiation
-    hipLaunchKernelGGL((k_log_part<TV, PASS>), dim3(persistent_blocks(blocks, fn, kPartThreads, lds)), dim3(kPartThreads), lds, s, L);
+    hipLaunchKernelGGL((k_log_part<TV, PASS, HOT>), dim3(persistent_blocks(blocks, fn, kPartThreads, lds)), dim3(kPartThreads), lds, s, L);
     return hipGetLastError();
 }
-template <int PASS> static hipError_t launch_part(const LogReduceParams& L, hipStream_t s)
+template <int PASS, bool HOT> static hipError_t launch_part(const LogReduceParams& L, hipStream_t s)
 {
-    if (L.tally == LT_TALLY_F32) return launch_part_t<float, PASS>(L, s);
-    if (L.tally == LT_TALLY_F64) return launch_part_t<double, PASS>(L, s);
-    return launch_part_t<unsigned long long, PASS>(L, s);
+    if (L.tally == LT_TALLY_F32) return launch_part_t<float, PASS, HOT>(L, s);
+    if (L.tally == LT_TALLY_F64) return launch_part_t<double, PASS, HOT>(L, s);
+    return launch_part_t<unsigned long long, PASS, HOT>(L, s);
 }
-hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s) { return launch_part<1>(L, s); }
+hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s)
+{
+    if (L.dmap) {
+        if (L.bits2 == 0 || L.n_tiles > kMaxHotTiles) return hipErrorInvalidValue;
+        return launch_part<1, true>(L, s);
+    }
+    return launch_part<1, false>(L, s);
+}
+hipError_t launch_log_count1(const LogReduceParams& L, hipStream_t s)
+{
+    if (!L.dmap || L.bits2 == 0 || L.n_tiles > kMaxHotTiles) return hipErrorInvalidValue;
+    const size_t lds = (size_t)kMaxBins * sizeof(uint32_t) + kMapLds;
+    const void* fn = reinterpret_cast<const void*>(&k_log_count1);
+    static std::atomic<unsigned> blocks{0};
+    const unsigned b = persistent_blocks(blocks, fn, kPartThreads, lds) / kLogGroups * kLogGroups;   // a workgroup serves one group
+    hipLaunchKernelGGL(k_log_count1, dim3(b < kLogGroups ? kLogGroups : b), dim3(kPartThreads), lds, s, L);
+    return hipGetLastError();
+}
 hipError_t launch_log_part2(const LogReduceParams& L, hipStream_t s)
 {
     // work units of pass 2, then the tiles of pass 1's output are counted per unit group: the scan of those counts
@@ -538,7 +664,7 @@ hipError_t launch_log_part2(const LogReduceParams& L, hipStream_t s)
     hipLaunchKernelGGL(k_log_count2, dim3(persistent_blocks(blocks, fn, kPartThreads, 0)), dim3(kPartThreads), 0, s, L);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = launch_log_scan_tiles(L, s)) != hipSuccess) return e;
-    return launch_part<2>(L, s);
+    return launch_part<2, false>(L, s);
 }
 
 template <typename TV> static hipError_t launch_reduce_t(const LogReduceParams& L, hipStream_t s)
