@@ -348,7 +348,11 @@ __global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogRed
         if (p < n) {
             const uint32_t kk = s_key[p];
             const uint32_t dg = digit(kk);
+#if defined(LT_PART_DEBUG)          /* timing experiments only (results are wrong): the sorted item goes back where it came from */
+            const uint32_t dst = ds.x + off + p;
+#else
             const uint32_t dst = s_b[dg] + p;
+#endif
             // the last pass leaves a tile's records together, so only the 14-bit position inside the tile is kept:
             // 2 bytes instead of 4 written here and read by the reduce.  (Hot tiles come first in pass 1's output, so
             // their 2-byte positions [0, 2 D) never meet the 4-byte indices of the bins behind them [4 D, ...).)
