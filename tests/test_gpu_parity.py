@@ -657,8 +657,8 @@ def test_light_subpath_vertices(ctx, name):
 def test_log_tally_equals_atomic_tally(ctx):
     """LT_MODE_LOG (deposit log -> tile partition -> LDS reduce) against LT_MODE_ATOMIC: bit-identical fixed-point
     grids -- with an ample log (one batch), with a log budget that forces several batches, with one so small that
-    most records overflow to the atomic fallback, with the batches alternating between the ctx's two lanes
-    (lt_set_overlap 2), with the two-pass partition forced on a small grid, and on a grid whose size is not a
+    most records overflow to the atomic fallback, with the batches alternating between two or three lanes of the ctx
+    (lt_set_overlap), with the two-pass partition forced on a small grid (hot-tile form and plain), and on a grid whose size is not a
     multiple of the 16384-voxel tile; float tallies equal up to summation order.  Every regime is checked to have
     really been exercised (batches, overflow, lanes reported by lt_last_log_info).  Fresh contexts: a log budget
     smaller than an earlier allocation must be honoured all the same."""
@@ -667,34 +667,48 @@ def test_log_tally_equals_atomic_tally(ctx):
                     layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))
     big = S.Problem([(0.1, 10.0, 0.9, 1.0)], (300, 300, 200), (-15.0, -15.0, 0.0), (0.1,) * 3,
                     layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))   # 1300 tiles: two-pass partition
-    regimes = (("atomic", 0, 1, None), ("log", 8 << 30, 1, None), ("log", 48 << 20, 1, None), ("log", 4 << 20, 1, None),
-               ("log", 8 << 30, 2, None), ("log", 48 << 20, 2, None), ("log", 8 << 30, 1, "3"), ("log", 48 << 20, 2, "2"))
+    # (mode, log budget, lanes, LT_LOG_BITS2, LT_LOG_HOT): the two-pass form runs with the hot tiles the pilot batch
+    # finds (default), with a handful of them, and without (plain two passes)
+    regimes = (("atomic", 0, 1, None, None), ("log", 8 << 30, 1, None, None), ("log", 48 << 20, 1, None, None),
+               ("log", 4 << 20, 1, None, None), ("log", 8 << 30, 2, None, None), ("log", 48 << 20, 2, None, "0"),
+               ("log", 8 << 30, 3, None, "5"), ("log", 8 << 30, 1, "3", None), ("log", 48 << 20, 2, "2", None),
+               ("log", 8 << 30, 1, "3", "0"), ("log", 48 << 20, 3, "2", "3"))
     for prob, n in ((S.slab(), 300000), (odd, 300000), (S.cornell(64), 100000), (big, 300000)):
         grids = {}
         c2 = lt.Context(0)        # ample logs first on the session ctx, small budgets later: both orders are covered
-        for k, (mode, log_bytes, lanes, bits2) in enumerate(regimes):
+        for k, (mode, log_bytes, lanes, bits2, hot) in enumerate(regimes):
             cx = ctx if k % 2 == 0 else c2
             if bits2 is not None:
                 os.environ["LT_LOG_BITS2"] = bits2
+            if hot is not None:
+                os.environ["LT_LOG_HOT"] = hot
             try:
                 prob.apply(cx, "u64fx"); cx.set_tally_mode(mode, log_bytes); cx.set_overlap(lanes)
                 cx.launch(n, seed=5); cx.sync()
             finally:
-                os.environ.pop("LT_LOG_BITS2", None)
-            grids[(mode, log_bytes, lanes, bits2)] = (cx.read_grid_raw(), cx.read_counters())
+                os.environ.pop("LT_LOG_BITS2", None); os.environ.pop("LT_LOG_HOT", None)
+            grids[(mode, log_bytes, lanes, bits2, hot)] = (cx.read_grid_raw(), cx.read_counters())
             info = cx.last_log_info()
             if mode == "atomic":
                 assert info is None
                 continue
             assert info["lanes"] == lanes and info["records"] + info["overflow_records"] > 50 * n
+            two_pass = bits2 is not None or prob is big
+            n_hot = cx.last_log_hot_tiles()[0]
+            if not two_pass or hot == "0":
+                assert n_hot == 0
+            elif hot is not None:
+                assert n_hot == int(hot)                    # (more than that many tiles hold records)
+            else:
+                assert n_hot >= 16
             if log_bytes == 8 << 30:
-                assert info["overflow_records"] == 0 and info["batches"] <= (2 if lanes == 1 else 10)   # (+ the pilot)
+                assert info["overflow_records"] == 0 and info["batches"] <= (2 if lanes == 1 else 12)   # (+ the pilot)
             if log_bytes == 48 << 20:
                 assert info["batches"] >= 4, info
             if log_bytes == 4 << 20:
                 assert info["overflow_records"] > info["records"], info       # most deposits took the atomic fallback
         c2.close()
-        ref, cref = grids[("atomic", 0, 1, None)]
+        ref, cref = grids[("atomic", 0, 1, None, None)]
         for k, (g, c) in grids.items():
             assert np.array_equal(g, ref), k
             assert c["steps"] == cref["steps"] and c["photons"] == n
@@ -713,11 +727,11 @@ def test_log_tally_equals_atomic_tally(ctx):
 
 
 def test_config5_geometry_512_cubed(ctx):
-    """BASELINE config 5 at its own shape: two-layer skin model on a 512^3 grid of 0.025 mm voxels (16384 tiles:
-    two-pass partition with 128 level-1 bins, tile counting, 1 GiB of u64 tally).  (a) <= 2e4 photons: fixed-point
-    grid and step count equal the CPU oracle's bit for bit; (b) 2e6 photons: log == atomic bit for bit, one lane ==
-    two lanes, energy conservation, one launch == three ragged shards; the photon ids of (b) are those a rank of the
-    8-GPU run would trace (offset 3 * 1.25e7)."""
+    """BASELINE config 5 at its own shape: two-layer skin model on a 512^3 grid of 0.025 mm voxels (8192 tiles:
+    two-pass partition with 64 level-1 bins and up to 960 hot tiles, tile counting, 1 GiB of u64 tally).  (a) <= 2e4
+    photons: fixed-point grid and step count equal the CPU oracle's bit for bit; (b) 2e6 photons: log == atomic bit for
+    bit, one lane == two == three lanes, hot-tile form == plain two-pass form, energy conservation, one launch == three
+    ragged shards; the photon ids of (b) are those a rank of the 8-GPU run would trace (offset 3 * 1.25e7)."""
     prob = S.two_layer(n=512, voxel=0.025)
     n = 20000
     prob.apply(ctx, "u64fx"); ctx.set_tally_mode("log")
@@ -730,14 +744,21 @@ def test_config5_geometry_512_cubed(ctx):
     del fxo
     n, off = 2 * 10 ** 6, 3 * 12500000
     grids = {}
-    for mode, lanes in (("atomic", 1), ("log", 1), ("log", 2)):
-        prob.apply(ctx, "u64fx"); ctx.set_tally_mode(mode); ctx.set_overlap(lanes)
-        ctx.launch(n, seed=12, photon_offset=off); ctx.sync()
-        grids[(mode, lanes)] = (ctx.read_grid_raw(), ctx.read_counters())
+    for mode, lanes, hot in (("atomic", 1, None), ("log", 1, None), ("log", 2, None), ("log", 1, "0"), ("log", 3, "100")):
+        if hot is not None:
+            os.environ["LT_LOG_HOT"] = hot
+        try:
+            prob.apply(ctx, "u64fx"); ctx.set_tally_mode(mode); ctx.set_overlap(lanes)
+            ctx.launch(n, seed=12, photon_offset=off); ctx.sync()
+        finally:
+            os.environ.pop("LT_LOG_HOT", None)
+        grids[(mode, lanes, hot)] = (ctx.read_grid_raw(), ctx.read_counters())
         if mode == "log":
             info = ctx.last_log_info()
             assert info["lanes"] == lanes and info["overflow_records"] == 0, info
-    ref, cref = grids[("atomic", 1)]
+            n_hot = ctx.last_log_hot_tiles()[0]      # 8192 tiles, 64 level-1 bins: up to 960 hot tiles
+            assert (n_hot == int(hot)) if hot is not None else (900 <= n_hot <= 960), n_hot
+    ref, cref = grids[("atomic", 1, None)]
     assert cref["photons"] == n and abs(O.conservation_residual(cref)) < 1e-9 * n
     assert abs(float(ref.sum()) / O.FX_SCALE - cref["w_absorbed"]) < 1e-6 * n
     for k, (g, c) in grids.items():
