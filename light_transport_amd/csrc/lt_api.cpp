@@ -391,12 +391,14 @@ int plan_log(lt_ctx* c, uint64_t n, int lanes, LogPlan* plan)
     if (per_lane < 16 * (size_t)kLogChunk) return c->fail(LT_E_INVALID, "lt_launch: log budget too small (%zu bytes)", c->log_budget);
     // no measurement yet (pilot or tiny launch): tissue-like media give 100-400 records per photon
     const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 400.0;
-    // overlapped launches: sub-batches per launch.  Every batch ends in a drain of its longest photons and the last
-    // one's reduction has nothing to hide under: 4 measured best on C2 and on the 512^3 share (2: 43.2, 4: 41.9,
-    // 8: 46.9, 16: 57 ms per C2 job)
-    int sub = lanes == 3 ? 6 : 4;
-    if (const char* e = std::getenv("LT_OVERLAP_BATCHES")) { int v = std::atoi(e); if (v >= 2 && v <= 256) sub = v; }
-    const uint64_t b_target = lanes == 1 ? n : (n + (uint64_t)sub - 1) / (uint64_t)sub;
+    // Overlapped launches: every lane starts with one large batch (the walks run side by side at full occupancy), then
+    // ONE small batch follows whose walk runs beside the first reductions and whose own reduction is all that is left
+    // exposed at the end: relative sizes 2 : 2 : 1 on two lanes.  Every further batch costs a drain of its longest
+    // photons and a pipeline fill; interleaved in one process (tools/pattern_ab.py, profiles/r02c_batch_layout.log):
+    // C2 2,2,1: 40.2 ms, staggered 1,2,2,1: 40.8, five staggered batches: 41.8; 512^3 share 61.5 / 63.1 / 63.0 ms.
+    // LT_OVERLAP_PATTERN="w0,w1,..." (relative sizes, dealt to the lanes in turn) overrides the layout for tuning.
+    const uint64_t tail = lanes == 1 ? 0 : n / (uint64_t)(2 * lanes + 1);
+    const uint64_t b_target = lanes == 1 ? n : (n - tail + (uint64_t)lanes - 1) / (uint64_t)lanes;
     // every resident walk wave holds one partly filled chunk: that many chunks are claimed on top of the records' own
     double waves = 20.0 * (double)c->prop.multiProcessorCount / (double)lanes;          // at most 5 waves per SIMD
     const double launched = 4.0 * (double)((b_target + 255) / 256);                          // 256-thread workgroups
@@ -425,15 +427,32 @@ int plan_log(lt_ctx* c, uint64_t n, int lanes, LogPlan* plan)
     if (lanes == 1) {
         while (left > 0) { const uint64_t b = (double)left > fit ? (uint64_t)fit : left; plan->batches.emplace_back(0, b); left -= b; }
     } else {
-        uint64_t b = (double)b_target > fit ? (uint64_t)fit : b_target;
-        if (b < 1) b = 1;
-        // the lanes' first batches are b/L, 2b/L, ... b, so that they fall out of step: from then on one lane's
-        // reduction runs beside the other lanes' walks
-        int l = 0, first_round = lanes;
+        int l = 0;
+        if (const char* e = std::getenv("LT_OVERLAP_PATTERN")) {
+            std::vector<double> wts; double sum = 0.0;
+            for (const char* q = e; *q;) { char* end = nullptr; const double v_ = std::strtod(q, &end); if (end == q) break; if (v_ > 0) { wts.push_back(v_); sum += v_; } q = *end ? end + 1 : end; }
+            for (size_t k = 0; k < wts.size() && left > 0 && sum > 0; k++) {
+                uint64_t take = k + 1 == wts.size() ? left : (uint64_t)((double)n * wts[k] / sum);
+                if (take < 1) take = 1;
+                if (take > left) take = left;
+                if ((double)take > fit) take = (uint64_t)fit;
+                plan->batches.emplace_back(l, take);
+                left -= take; l = (l + 1) % lanes;
+            }
+        }
+        // the body in equal batches (a multiple of the lane count, each within the log), then the tail
+        const uint64_t body = left > tail ? left - tail : left;
+        const uint64_t cap_b = (double)b_target > fit ? (uint64_t)fit : b_target;
+        uint64_t rounds = (body + cap_b * (uint64_t)lanes - 1) / (cap_b * (uint64_t)lanes);
+        if (rounds < 1) rounds = 1;
+        const uint64_t full = (body + rounds * (uint64_t)lanes - 1) / (rounds * (uint64_t)lanes);
+        for (uint64_t k = 0, done_b = 0; k < rounds * (uint64_t)lanes && done_b < body; k++) {
+            const uint64_t take = full < body - done_b ? full : body - done_b;
+            plan->batches.emplace_back(l, take);
+            done_b += take; left -= take; l = (l + 1) % lanes;
+        }
         while (left > 0) {
-            uint64_t take = b;
-            if (first_round > 0) { take = b * (uint64_t)(l + 1) / (uint64_t)lanes; if (take < 1) take = 1; first_round--; }
-            if (take > left) take = left;
+            const uint64_t take = (double)left > fit ? (uint64_t)fit : left;
             plan->batches.emplace_back(l, take);
             left -= take; l = (l + 1) % lanes;
         }
