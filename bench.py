@@ -436,25 +436,34 @@ def main(argv=None):
             rec = float(np.mean([x["records"] for x in stages]))
             rb_ = 4 + REC_VALUE_BYTES[args.tally]                              # bytes per deposit record in the log
             passes = 2 if wl["grid"] ** 3 > 1024 * 16384 else 1
-            part_bytes = rec * ((2 * rb_ - 2) if passes == 1 else (2 * rb_ + 4 + 2 * rb_ - 2))   # + pass 2 and the tile count's index read
+            # algorithmic bytes of the partition: every record read once and written once in its final form.  (Grids of
+            # more than 1024 tiles really move more: a 4-byte index read to count the digits, and a second pass over the
+            # records of the tiles that are not hot -- that surplus counts against the kernel, not for it.)
+            part_bytes = rec * (2 * rb_ - 2)
             out["roofline"]["deposit_records_per_launch"] = rec
+            if hasattr(pool[0], "last_log_hot_tiles"):       # grids of > 1024 tiles: tiles that skip the second partition pass
+                try:
+                    out["roofline"]["hot_tiles"] = pool[0].last_log_hot_tiles()[0]
+                except Exception:
+                    pass
             out["roofline"]["kernels_overlapped_ms"] = {
                 k: float(np.mean([x[k] for x in stages])) for k in ("walk_ms", "partition_ms", "reduce_ms")}
             out["roofline"]["kernels_overlapped_ms"]["note"] = (
                 "sums of the kernels' own event-to-event times over the timed region; with several jobs / lanes in "
                 "flight these overlap in time and are NOT per-step kernel times")
             if alone and "walk_ms" in alone:
-                w, p_, r_ = alone["walk_ms"], alone["partition_ms"], alone["reduce_ms"]
+                w, p_, r_ = alone["walk_ms"], alone["partition_ms"] + (alone.get("scan_ms", 0.0) if passes == 2 else 0.0), alone["reduce_ms"]
                 out["roofline"]["kernels"] = [
                     {"kernel": "walk_kernel", "ms": w, "bound": "valu", "regime": "one job alone",
                      "note": "~350 VALU instr per photon-step (PMC SQ_INSTS_VALU); writes the %.1f GB deposit log" % (rec * rb_ / 1e9),
                      "photon_steps_per_sec": steps_one_launch / (w * 1e-3)},
-                    {"kernel": "k_log_part (+ k_log_count2)" if passes == 2 else "k_log_part", "ms": p_, "bound": "hbm",
+                    {"kernel": "k_log_count1 + k_log_part<1> + k_log_count2 + k_log_part<2>" if passes == 2 else "k_log_part", "ms": p_, "bound": "hbm",
                      "regime": "one job alone", "achieved": part_bytes / (p_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": part_bytes / (p_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "note": "algorithmic: %s" % ("every record read once (%d B) and written once (%d B: 2-byte in-tile position)" % (rb_, rb_ - 2)
-                                                  if passes == 1 else
-                                                  "two passes: %d B read + %d B written, 4 B index re-read for the tile count, %d B read + %d B written" % (rb_, rb_, rb_, rb_ - 2))},
+                     "note": "algorithmic: every record read once (%d B) and written once (%d B: 2-byte in-tile position)%s" % (
+                         rb_, rb_ - 2, "" if passes == 1 else
+                         "; this grid has more than 1024 tiles: on top of that the digits are counted from the log (4 B index read) "
+                         "and the records of the tiles that are not hot (lt_last_log_hot_tiles) take a second pass")},
                     {"kernel": "k_log_reduce", "ms": r_, "bound": "hbm", "regime": "one job alone",
                      "achieved": (rb_ - 2) * rec / (r_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (rb_ - 2) * rec / (r_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -469,7 +478,7 @@ def main(argv=None):
                 "note": "mean over EVERY dispatch this process made (probe, warm-up, timed, reference launches; sub-batches "
                         "and pilot batches count as dispatches): the number a rocprofv3 --kernel-trace --stats summary of the "
                         "same command reports as AverageNs (profiles/*_kernel_stats.csv); %s" % (
-                            "k_log_part<.,1> + k_log_count2 + k_log_part<.,2> are separate rows there" if passes_ == 2 else
+                            "k_log_part<.,1,.> + k_log_count2 + k_log_part<.,2,.> are separate rows there (k_log_count1 belongs to the scan stage)" if passes_ == 2 else
                             "one partition dispatch per batch")}
         if alone:
             alone["note"] = ("one job alone on the device, one lane (default launch geometry, 4 waves/SIMD), 2 launches after the "

@@ -1,6 +1,6 @@
 """Same-process A/B of the sub-batch layout of an overlapped launch (lt_set_overlap 2): the environment knobs are read
 at every lt_launch, so the variants are interleaved launch by launch and compared by their median device time.
-    python tools/pattern_ab.py [c2|c5] [reps]"""
+    python tools/pattern_ab.py [c2|c5] [reps] [lanes:PATTERN=2,2,1 ...]"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import light_transport_amd as lt
@@ -9,10 +9,11 @@ from tests import scenes as S
 which = sys.argv[1] if len(sys.argv) > 1 else "c2"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 prob, n = {"c2": (S.slab(n=256, voxel=0.1), 10 ** 7), "c5": (S.two_layer(n=512, voxel=0.025), 12500000)}[which]
-variants = [("BATCHES", "4"), ("PATTERN", "2,2,1"), ("PATTERN", "3,3,1"), ("PATTERN", "4,4,1"), ("PATTERN", "3,3,2"), ("PATTERN", "2,2,1,1"),
-            ("PATTERN", "4,4,2,1"), ("PATTERN", "3,3,2,1"), ("PATTERN", "5,5,3,2"), ("PATTERN", "6,6,3,2,1")]
+# (lanes, knob, value)
+variants = [(2, "PATTERN", "2,2,1"), (3, "PATTERN", "2,2,1"), (3, "PATTERN", "1,1,1"), (3, "PATTERN", "3,3,2"), (3, "PATTERN", "4,4,1"),
+            (3, "PATTERN", "2,2,2,1"), (3, "PATTERN", "3,3,1,1"), (2, "PATTERN", "5,5,2")]
 if len(sys.argv) > 3:
-    variants = [tuple(a.split("=")) for a in sys.argv[3:]]
+    variants = [(int(a.split(":")[0]),) + tuple(a.split(":")[1].split("=")) for a in sys.argv[3:]]
 ctx = lt.Context(0)
 prob.apply(ctx, "f64"); ctx.set_tally_mode("log"); ctx.set_overlap(2)
 ctx.launch(n, seed=0); ctx.sync()
@@ -20,10 +21,12 @@ times = {v: [] for v in variants}
 for r in range(reps):
     for v in variants:
         os.environ.pop("LT_OVERLAP_BATCHES", None); os.environ.pop("LT_OVERLAP_PATTERN", None)
-        os.environ["LT_OVERLAP_" + v[0]] = v[1]
+        os.environ["LT_OVERLAP_" + v[1]] = v[2]
+        ctx.set_overlap(v[0])
         ctx.zero_tally(); ctx.launch(n, seed=r + 1); ctx.sync()
-        times[v].append(ctx.last_kernel_ms())
+        if r:
+            times[v].append(ctx.last_kernel_ms())
 for v in variants:
     t = times[v]
-    print("%s %-8s %-9s median %.2f  min %.2f  max %.2f ms" % (which, v[0], v[1], statistics.median(t), min(t), max(t)), flush=True)
+    print("%s lanes %d %-8s %-9s median %.2f  min %.2f  max %.2f ms" % (which, v[0], v[1], v[2], statistics.median(t), min(t), max(t)), flush=True)
 ctx.close()
