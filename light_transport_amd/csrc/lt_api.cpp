@@ -122,6 +122,7 @@ struct lt_ctx {
     // counts a batch on lane 0 left behind (normally the pilot batch) and shared by every lane
     DevBuf d_dmap, d_dmeta;
     bool dmap_valid = false, tile_cnt_ready = false, last_hot = false;
+    uint32_t dmap_tiles = 0, dmap_bits2 = 0;      // the partition geometry the map was made for
     bool tables_dirty = true;
     bool timed = false;
 
@@ -911,6 +912,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     if (use_log) {
         LogRun R;
         R.c = c; R.P = P; R.v = v; R.cfg = cfg; R.G = G;
+        if (c->dmap_valid && (c->dmap_tiles != G.n_tiles || c->dmap_bits2 != G.bits2)) c->dmap_valid = c->tile_cnt_ready = false;   // (LT_LOG_BITS2 changed)
         c->stages_valid = false;
         for (LogLane& ln : c->lanes) ln.ev_used = 0;
         HIP_TRY(c, hipMemsetAsync(c->d_job.p, 0, 2 * sizeof(unsigned long long), c->stream));
@@ -940,7 +942,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
                 HIP_TRY(c, c->d_dmeta.ensure(4 * sizeof(uint32_t)));
                 HIP_TRY(c, launch_log_plan((const uint32_t*)c->lanes[0].tile_cnt.p, G.n_tiles, G.bits2, max_hot, (uint16_t*)c->d_dmap.p,
                                            (uint32_t*)c->d_dmeta.p, c->stream));
-                c->dmap_valid = true;
+                c->dmap_valid = true; c->dmap_tiles = G.n_tiles; c->dmap_bits2 = G.bits2;
             }
         }
         if (use_log) {
