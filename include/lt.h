@@ -152,7 +152,7 @@ int lt_set_launch_config(lt_ctx* ctx, int blocks_per_cu, int threads_per_block);
  * tiles (2^30 voxels) use the atomic path. */
 #define LT_MODE_ATOMIC 0
 #define LT_MODE_LOG 1
-#define LT_MODE_AUTO 2 /* default: LOG where the atomic unit would pace the walk (layered slabs, f32 mesh walks), ATOMIC for f64 mesh walks (BVH arithmetic hides the atomics) */
+#define LT_MODE_AUTO 2 /* default: LOG whenever the launch can use it (no RNG table, no vertex capture, grid within the tile index range, free HBM), ATOMIC otherwise */
 int lt_set_tally_mode(lt_ctx* ctx, int mode, uint64_t log_bytes);
 /* optional: allocate the deposit log(s) for launches of up to n_photons now (otherwise the first launch does it) */
 int lt_reserve_log(lt_ctx* ctx, uint64_t n_photons);

@@ -275,9 +275,11 @@ int upload_tables(lt_ctx* c)
                     c->ccell[k] = ext[k] > 0 ? ext[k] / c->cn[k] : h; c->corg[k] = c->nodes[0].lo[k];
                 }
                 const size_t cells = (size_t)c->cn[0] * c->cn[1] * c->cn[2];
-                HIP_TRY(c, c->d_clear.ensure(cells * sizeof(float)));
-                HIP_TRY(c, launch_build_clearance(c->d_tris[0].p, (int)t64.size(), (float*)c->d_clear.p, c->cn[0], c->cn[1], c->cn[2],
-                                                  c->corg, c->ccell, c->stream));
+                // 16 bytes per cell: the clearance and the cell's nearest triangles (WalkParams::clear; LT_NO_NEAR_LISTS=1
+                // leaves the lists empty, every query then walks the BVH)
+                HIP_TRY(c, c->d_clear.ensure(cells * 16));
+                HIP_TRY(c, launch_build_clearance(c->d_tris[0].p, (int)t64.size(), std::getenv("LT_NO_NEAR_LISTS") ? 0 : 1, c->d_clear.p,
+                                                  c->cn[0], c->cn[1], c->cn[2], c->corg, c->ccell, c->stream));
                 c->have_clear = true;
             }
         }
@@ -870,7 +872,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     P.max_steps = c->max_steps;
     P.counters = (DevCounters*)c->d_counters.p;
     if (c->have_mesh && c->have_clear) {
-        P.clear = (const float*)c->d_clear.p; P.cnx = c->cn[0]; P.cny = c->cn[1]; P.cnz = c->cn[2];
+        P.clear = (const uint4*)c->d_clear.p; P.cnx = c->cn[0]; P.cny = c->cn[1]; P.cnz = c->cn[2];
         for (int k = 0; k < 3; k++) { P.corg[k] = c->corg[k]; P.cinv[k] = 1.0 / c->ccell[k]; }
     }
     c->captured_photons = 0;
@@ -903,9 +905,10 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     if (cfg.blocks < 1) cfg.blocks = 1;
 
     // ---- log-structured tally: walk -> deposit log -> partition by grid tile -> LDS tile reduce, in batches
-    // auto: slab walks and f32 mesh walks are paced by the atomic unit -> log (C4, f32: 43 ms log vs 60 ms atomic);
-    // the f64 mesh walk's BVH arithmetic hides the atomics, so the log passes would only add time (58 vs 59 ms)
-    const int mode = c->tally_mode == 2 ? ((c->have_mesh && !v.f32) ? 0 : 1) : c->tally_mode;
+    // auto: every walk is paced by the atomic unit (~17-20e9 requests/s) when it deposits with atomics -> log.  (Until
+    // the near-triangle lists the f64 mesh walk was the exception: its BVH arithmetic hid the atomics, 58 vs 59 ms on
+    // C4; with them: 53.8 ms atomic, 44.3 ms log.)
+    const int mode = c->tally_mode == 2 ? 1 : c->tally_mode;
     { int rc3 = collect_log_stats(c); if (rc3) return rc3; }   // stats of the previous launch size this one
     LogGeom G = log_geom(c);
     bool use_log = mode == 1 && !v.table && c->max_vertices == 0 && G.n_tiles <= kMaxLogTiles && !std::getenv("LT_DIAG_NO_TALLY");

@@ -95,9 +95,13 @@ struct WalkParams {
                           // the level-1 digit of the two-pass partition otherwise (<= 128 bins: 512 B of LDS)
     uint32_t log_n_hist, log_hist_shift, log_ntx, log_nty;
     uint32_t* log_overflow;   // [1] records that found the log full and went to the grid as global atomics
-    // clearance grid (mesh scenes; null = off): conservative lower bound of the distance from any point of a cell
-    // to any triangle -- a hop shorter than that cannot hit, so the BVH query is skipped
-    const float* clear;
+    // clearance grid (mesh scenes; null = off), one 16-byte record per cell:
+    //   x  c0 (f32 bits): conservative lower bound of the distance from any point of the cell to any triangle -- a hop
+    //      shorter than that cannot hit, so no query is made at all;
+    //   y  c2 | c4 << 16 (f16, rounded down): the same bound for the 3rd / the 5th nearest triangle -- a hop shorter
+    //      than c2 (c4) can only hit the 2 (4) nearest ones, which are tested directly instead of walking the BVH;
+    //   z  id0 | id1 << 16,  w  id2 | id3 << 16: those triangles, nearest first (0xffff: none)
+    const uint4* clear;
     int cnx, cny, cnz;
     double corg[3], cinv[3];
     // light sub-path capture (null = off)
@@ -143,7 +147,7 @@ struct RenderParams {
     int choices;   // variant 1: light_choice entries per sample
 };
 constexpr int kRenderOldMaxDepth = 24;   // frames of the unrolled recursion (variant 1)
-hipError_t launch_build_clearance(const void* tris_f64, int n_tris, float* clear, int nx, int ny, int nz,
+hipError_t launch_build_clearance(const void* tris_f64, int n_tris, int near_lists, void* clear_records, int nx, int ny, int nz,
                                   const double org[3], const double cell[3], hipStream_t s);
 hipError_t launch_render_surface(const RenderParams& P, hipStream_t s);
 

@@ -314,6 +314,31 @@ LT_DEV void nearest_brute(const TriD<R>* tris, int n_tris, const R* o, const R* 
     prim = bi; t_out = bi >= 0 ? bt : Mx<R>::inf();
 }
 
+// A query whose hop is shorter than the cell's c2 (c4) bound can only hit the 2 (4) triangles listed in the cell's
+// clearance record (WalkParams::clear): they are tested directly -- same tri_hit, same nearest / tie rule, hence the
+// same answer as the BVH walk, which is left to the hops that reach farther.
+template <typename R>
+LT_DEV void nearest_listed(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes, const uint4 rec, const R* o,
+                           const R* d, R tmax, int& prim, R& t_out)
+{
+    const float c2 = (float)__builtin_bit_cast(_Float16, (unsigned short)(rec.y & 0xffffu));
+    const float c4 = (float)__builtin_bit_cast(_Float16, (unsigned short)(rec.y >> 16));
+    if (tmax < (R)c4) {
+        int bi = -1; R bt = tmax;
+        const int i0 = (int)(rec.z & 0xffffu), i1 = (int)(rec.z >> 16);
+        if (i0 != 0xffff) consider(tris, i0, o, d, bi, bt);
+        if (i1 != 0xffff) consider(tris, i1, o, d, bi, bt);
+        if (!(tmax < (R)c2)) {
+            const int i2 = (int)(rec.w & 0xffffu), i3 = (int)(rec.w >> 16);
+            if (i2 != 0xffff) consider(tris, i2, o, d, bi, bt);
+            if (i3 != 0xffff) consider(tris, i3, o, d, bi, bt);
+        }
+        prim = bi; t_out = bi >= 0 ? bt : Mx<R>::inf();
+    } else {
+        nearest_bvh(tris, nodes, n_nodes, o, d, tmax, prim, t_out);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // sampling
 // ---------------------------------------------------------------------------
@@ -604,9 +629,12 @@ constexpr unsigned kPacket = 64;  // photon ids taken from the global queue per 
 #endif
 constexpr unsigned kRefillMin = LT_REFILL_MIN;   // dead lanes a wave collects before it refills them
 #ifndef LT_QUERY_MIN
-#define LT_QUERY_MIN 16
+#define LT_QUERY_MIN 8
 #endif
-constexpr unsigned kQueryMin = LT_QUERY_MIN;     // mesh walks: lanes a wave collects before it runs their BVH queries
+// mesh walks: lanes a wave collects before it serves their surface queries.  16 was best while every query walked the
+// BVH (~1500 instructions per service); with the near-triangle lists (nearest_listed: ~2-4 triangle tests) a service is
+// cheap and waiting costs more: C4 f64 walk 37.3 ms at 16, 34.4 at 8, 34.5 at 4, 47.6 at 32 (profiles/r02d_c4_near_lists.log)
+constexpr unsigned kQueryMin = LT_QUERY_MIN;
 
 // ---------------------------------------------------------------------------
 // the walk kernel
@@ -876,30 +904,63 @@ LT_DEV double point_tri_dist2(const double* p, const TriD<double>& T)
     return dot3(e, e);
 }
 
-__global__ void k_build_clearance(const TriD<double>* tris, int n_tris, float* clear, int nx, int ny, int nz,
+// f16 <-> f32 for the clearance records (values >= 0; encode rounds toward zero so that the bound stays conservative)
+LT_DEV unsigned half_down(double c)
+{
+    if (!(c > 0)) return 0u;
+    if (!(c < 65504.0)) return c == __builtin_huge_val() ? 0x7c00u : 0x7bffu;
+    _Float16 h = (_Float16)(float)c;
+    unsigned short b = __builtin_bit_cast(unsigned short, h);
+    if ((double)(float)h > c && b > 0) b--;
+    return b;
+}
+LT_DEV float half_up(unsigned bits) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(bits & 0xffffu)); }
+
+__global__ void k_build_clearance(const TriD<double>* tris, int n_tris, int near_lists, uint4* clear, int nx, int ny, int nz,
                                   double ox, double oy, double oz, double hx, double hy, double hz)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)nx * ny * nz) return;
     const int ix = (int)(i % nx), iy = (int)((i / nx) % ny), iz = (int)(i / ((size_t)nx * ny));
     const double p[3] = {ox + (ix + 0.5) * hx, oy + (iy + 0.5) * hy, oz + (iz + 0.5) * hz};
-    double best = __builtin_huge_val();
-    for (int t = 0; t < n_tris; t++) { const double d2 = point_tri_dist2(p, tris[t]); best = d2 < best ? d2 : best; }
+    // the five nearest triangles of the cell centre, nearest first (squared distances; ties keep the lower index first)
+    const double inf = __builtin_huge_val();
+    double best[5] = {inf, inf, inf, inf, inf};
+    int id[5] = {-1, -1, -1, -1, -1};
+    for (int t = 0; t < n_tris; t++) {
+        double d2 = point_tri_dist2(p, tris[t]);
+        int ti = t;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (d2 < best[k]) { const double sd = best[k]; const int si = id[k]; best[k] = d2; id[k] = ti; d2 = sd; ti = si; }
+    }
     const double half_diag = 0.5 * ::sqrt(hx * hx + hy * hy + hz * hz);
-    double c = (::sqrt(best) - half_diag) * (1.0 - 1e-6) - 1e-7 * (hx + hy + hz);   // strictly conservative
-    float f = c > 0 ? (float)c : 0.0f;
-    if ((double)f > c && f > 0) f = __uint_as_float(__float_as_uint(f) - 1u);      // round toward zero
-    clear[i] = f;
+    auto bound = [&](double d2) -> double {     // strictly conservative for every point of the cell
+        if (d2 == inf) return inf;
+        const double c = (::sqrt(d2) - half_diag) * (1.0 - 1e-6) - 1e-7 * (hx + hy + hz);
+        return c > 0 ? c : 0.0;
+    };
+    const double c0 = bound(best[0]);
+    float f = (float)c0;
+    if ((double)f > c0 && f > 0) f = __uint_as_float(__float_as_uint(f) - 1u);      // round toward zero
+    if (c0 == inf) f = 3.0e38f;
+    unsigned y = 0, z = 0xffffffffu, w = 0xffffffffu;
+    if (near_lists && n_tris <= 0xffff) {
+        y = half_down(bound(best[2])) | (half_down(bound(best[4])) << 16);
+        z = (unsigned)(id[0] & 0xffff) | ((unsigned)(id[1] & 0xffff) << 16);      // (-1 & 0xffff = 0xffff: none)
+        w = (unsigned)(id[2] & 0xffff) | ((unsigned)(id[3] & 0xffff) << 16);
+    }
+    clear[i] = make_uint4(__float_as_uint(f), y, z, w);
 }
 
-hipError_t launch_build_clearance(const void* tris_f64, int n_tris, float* clear, int nx, int ny, int nz,
+hipError_t launch_build_clearance(const void* tris_f64, int n_tris, int near_lists, void* clear_records, int nx, int ny, int nz,
                                   const double org[3], const double cell[3], hipStream_t s)
 {
     const size_t n = (size_t)nx * ny * nz;
     if (n == 0 || n_tris <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_build_clearance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                       reinterpret_cast<const TriD<double>*>(tris_f64), n_tris, clear, nx, ny, nz, org[0], org[1], org[2],
-                       cell[0], cell[1], cell[2]);
+                       reinterpret_cast<const TriD<double>*>(tris_f64), n_tris, near_lists, reinterpret_cast<uint4*>(clear_records), nx, ny, nz,
+                       org[0], org[1], org[2], cell[0], cell[1], cell[2]);
     return hipGetLastError();
 }
 

@@ -897,6 +897,32 @@ def test_random_layered_scenes_match_oracle(ctx):
     ctx.set_tally_mode(2)
 
 
+def test_surface_query_shortcuts_do_not_change_results(ctx):
+    """Mesh walks skip the BVH when the cell's clearance says no surface is within the hop, and test only the cell's
+    listed nearest triangles when nothing else is (WalkParams::clear records): both are shortcuts, not approximations.
+    u64 grids and step counts with the lists off (LT_NO_NEAR_LISTS=1), with the clearance grid off altogether
+    (LT_NO_CLEARANCE=1: every step queries the BVH) and with a coarse / a fine grid are identical bit for bit, on the
+    Cornell cavity + cone (30 triangles in LDS, area source) and on the 5140-triangle sphere (tables in global memory)."""
+    cases = ((S.cornell(64), 200000), (S.sphere_in_box(4, split_method=0)[0], 60000))
+    variants = ({}, {"LT_NO_NEAR_LISTS": "1"}, {"LT_NO_CLEARANCE": "1"}, {"LT_CLEARANCE_CELLS": "16"}, {"LT_CLEARANCE_CELLS": "200"})
+    for prob, n in cases:
+        ref = None
+        for env in variants:
+            os.environ.update(env)
+            try:
+                prob.apply(ctx, "u64fx"); ctx.set_tally_mode("atomic")
+                ctx.launch(n, seed=21); ctx.sync()
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+            g, c = ctx.read_grid_raw(), ctx.read_counters()
+            if ref is None:
+                ref = (g, c)
+                assert c["w_escaped_mesh"] > 0 and g.sum() > 0
+            assert c["steps"] == ref[1]["steps"] and np.array_equal(g, ref[0]), env
+    ctx.set_tally_mode(2)
+
+
 def test_random_mesh_scenes_match_oracle(ctx):
     """Randomised closed-box + sphere scenes (sphere size, position, tessellation, media, indices, source, BVH split
     method drawn at random), both tally paths, f64 walk: fixed-point tallies and step counts equal the oracle's.  These
