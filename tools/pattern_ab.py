@@ -8,7 +8,8 @@ from tests import scenes as S
 
 which = sys.argv[1] if len(sys.argv) > 1 else "c2"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-prob, n = {"c2": (S.slab(n=256, voxel=0.1), 10 ** 7), "c5": (S.two_layer(n=512, voxel=0.025), 12500000)}[which]
+prob, n = {"c2": (S.slab(n=256, voxel=0.1), 10 ** 7), "c5": (S.two_layer(n=512, voxel=0.025), 12500000),
+           "c4": (S.cornell(256), 10 ** 7)}[which]
 # (lanes, knob, value)
 variants = [(2, "PATTERN", "2,2,1"), (3, "PATTERN", "2,2,1"), (3, "PATTERN", "1,1,1"), (3, "PATTERN", "3,3,2"), (3, "PATTERN", "4,4,1"),
             (3, "PATTERN", "2,2,2,1"), (3, "PATTERN", "3,3,1,1"), (2, "PATTERN", "5,5,2")]
