@@ -292,6 +292,46 @@ def test_c2_full_size_properties(ctx):
     assert np.array_equal(a, ctx.read_grid_raw())
 
 
+@pytest.mark.parametrize("name", ["c3", "c4"])
+def test_c3_c4_full_size_properties(ctx, name):
+    """BASELINE configs 3 (two-layer slab) and 4 (mesh + BVH) at their own size -- 1e7 photons, 256^3: energy
+    conservation, one launch == three ragged shards, log tally == atomic tally (u64 fixed point, bit for bit); for the
+    mesh also == the walk with every surface-query shortcut switched off (2e6 photons)."""
+    prob = S.two_layer(n=256, voxel=0.05) if name == "c3" else S.cornell(256)
+    n = 10 ** 7
+    prob.apply(ctx, "u64fx"); ctx.set_tally_mode("log")
+    ctx.launch(n, seed=3); ctx.sync()
+    whole, c = ctx.read_grid_raw(), ctx.read_counters()
+    assert ctx.last_log_info() is not None
+    assert c["photons"] == n and abs(O.conservation_residual(c)) < 1e-9 * n
+    assert abs(float(whole.sum()) / O.FX_SCALE - c["w_absorbed"]) < 1e-6 * n
+    if name == "c4":
+        assert c["w_escaped_mesh"] > 0.1 * n and 140 < c["steps"] / n < 156
+    else:
+        assert 260 < c["steps"] / n < 282
+    ctx.zero_tally()
+    for off, cnt in ((0, 2345678), (2345678, 4000001), (6345679, n - 6345679)):
+        ctx.launch(cnt, seed=3, photon_offset=off)
+    ctx.sync()
+    assert np.array_equal(whole, ctx.read_grid_raw()) and ctx.read_counters()["steps"] == c["steps"]
+    prob.apply(ctx, "u64fx"); ctx.set_tally_mode("atomic")
+    ctx.launch(n, seed=3); ctx.sync()
+    assert np.array_equal(whole, ctx.read_grid_raw()) and ctx.read_counters()["steps"] == c["steps"]
+    if name == "c4":
+        m = 2 * 10 ** 6
+        ctx.zero_tally(); ctx.launch(m, seed=4); ctx.sync()
+        a, ca = ctx.read_grid_raw(), ctx.read_counters()
+        os.environ["LT_NO_CLEARANCE"] = "1"
+        try:
+            prob.apply(ctx, "u64fx"); ctx.set_tally_mode("atomic")
+            ctx.launch(m, seed=4); ctx.sync()
+        finally:
+            os.environ.pop("LT_NO_CLEARANCE", None)
+        assert np.array_equal(a, ctx.read_grid_raw()) and ctx.read_counters()["steps"] == ca["steps"]
+        prob.apply(ctx, "u64fx")      # (tables with the clearance grid again for whoever uses the session ctx next)
+    ctx.set_tally_mode(2)
+
+
 def test_f32_tally_full_size_symmetry(ctx):
     prob = S.slab(n=255, voxel=0.1)   # odd: beam axis through the middle of column 127
     n = 4 * 10 ** 6
