@@ -10,7 +10,8 @@ if sys.argv[1] == "run":
     lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     case = sys.argv[3] if len(sys.argv) > 3 else "c2"
     prob, n, mode = {"c2": (S.slab(n=256, voxel=0.1), 10 ** 7, "log"), "c3": (S.two_layer(n=256, voxel=0.05), 10 ** 7, "log"),
-                     "c4": (S.cornell(256), 10 ** 7, "auto"), "c5": (S.two_layer(n=512, voxel=0.025), 12500000, "log")}[case]
+                     "c4": (S.cornell(256), 10 ** 7, "auto"), "c5": (S.two_layer(n=512, voxel=0.025), 12500000, "log"),
+                     "sphere": (S.sphere_in_box(4, split_method=0)[0], 10 ** 7, "log")}[case]
     ctx = lt.Context(0)
     prob.apply(ctx, "f64"); ctx.set_tally_mode(mode); ctx.set_overlap(lanes)
     for r in range(3):
