@@ -6,7 +6,7 @@ WL=${1:-c2}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py --workload $WL 2>&1 | tee gpurun_out/bench_$WL.log &&
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace_$WL -- python3 bench.py --workload $WL --steps 10 --warmup 2 --no-cpu-baseline --no-alone > gpurun_out/prof_trace_$WL.log 2>&1 &&
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace_$WL -- python3 bench.py --workload $WL > gpurun_out/prof_trace_$WL.log 2>&1 &&
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch_$WL -- python3 bench.py --workload $WL --inflight 1 --overlap 1 --steps 2 --warmup 1 --no-cpu-baseline --no-alone > gpurun_out/prof_fetch_$WL.log 2>&1 &&
 rocprofv3 --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d gpurun_out/prof_write_$WL -- python3 bench.py --workload $WL --inflight 1 --overlap 1 --steps 2 --warmup 1 --no-cpu-baseline --no-alone > gpurun_out/prof_write_$WL.log 2>&1 &&
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/prof_sq_$WL -- python3 bench.py --workload $WL --inflight 1 --overlap 1 --steps 2 --warmup 1 --no-cpu-baseline --no-alone > gpurun_out/prof_sq_$WL.log 2>&1
