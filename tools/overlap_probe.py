@@ -1,6 +1,6 @@
 """Two contexts on one GPU, steps alternating between them (each context has its own stream, log and grid): does the
 log reduction of step k overlap the walk of step k+1?  Prints ms per step for depth 1 (serial) and depth 2.
-    python tools/overlap_probe.py [steps] [photons]"""
+    python tools/overlap_probe.py [steps] [photons] [DxB,...]      (D contexts, walk at B workgroups per CU; 0 = all)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +9,8 @@ from tests import scenes as S
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 10 ** 7
-prob = S.slab(n=256, voxel=0.1)
+# LT_PROBE_SCENE=c4: the Cornell cavity + cone (mesh walk) instead of the C2 slab
+prob = S.cornell(256) if os.environ.get("LT_PROBE_SCENE") == "c4" else S.slab(n=256, voxel=0.1)
 
 
 def run(depth, tally="f64", f32=False, bpc=0):
