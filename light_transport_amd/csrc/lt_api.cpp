@@ -871,6 +871,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     P.table = (const double*)c->d_table.p; P.table_steps = table_steps;
     P.max_steps = c->max_steps;
     P.counters = (DevCounters*)c->d_counters.p;
+    if (const char* e = std::getenv("LT_QUERY_MIN")) { const int v_ = std::atoi(e); if (v_ >= 1 && v_ <= 64) P.query_min = (unsigned)v_; }
     if (c->have_mesh && c->have_clear) {
         P.clear = (const uint4*)c->d_clear.p; P.cnx = c->cn[0]; P.cny = c->cn[1]; P.cnz = c->cn[2];
         for (int k = 0; k < 3; k++) { P.corg[k] = c->corg[k]; P.cinv[k] = 1.0 / c->ccell[k]; }

@@ -82,6 +82,7 @@ struct WalkParams {
     const double* table;
     unsigned long long table_steps;
     unsigned max_steps;
+    unsigned query_min;   // mesh walks: lanes of a wave that wait for a surface query before it is served (0: the built-in default)
     DevCounters* counters;
     // log-structured tally (null = deposit with global atomics): coalesced deposit log written by the walk,
     // reduced into the grid by the partition / tile-reduce kernels

@@ -635,6 +635,11 @@ constexpr unsigned kRefillMin = LT_REFILL_MIN;   // dead lanes a wave collects b
 // BVH (~1500 instructions per service); with the near-triangle lists (nearest_listed: ~2-4 triangle tests) a service is
 // cheap and waiting costs more: C4 f64 walk 37.3 ms at 16, 34.4 at 8, 34.5 at 4, 47.6 at 32 (profiles/r02d_c4_near_lists.log)
 constexpr unsigned kQueryMin = LT_QUERY_MIN;
+// ... and when the tables live in global memory (GEOM 2): there a service that has to walk the BVH for some lane is a
+// chain of dependent loads that costs the wave the same whether 2 lanes or 20 walk, so it pays to wait for many: on the
+// 5140-triangle sphere 8 / 16 / 24 / 32 / 48 / 56 / 64 lanes give 4.7 / 5.4 / 6.3 / 7.1 / 8.5 / 8.2 / 5.2e9
+// photon-steps/s f64 (profiles/r02e_large_mesh_query_threshold.log).  LT_QUERY_MIN in the environment overrides both.
+constexpr unsigned kQueryMinGlobal = 48;
 
 // ---------------------------------------------------------------------------
 // the walk kernel
