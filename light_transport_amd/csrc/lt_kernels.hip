@@ -640,6 +640,14 @@ constexpr unsigned kQueryMin = LT_QUERY_MIN;
 // 5140-triangle sphere 8 / 16 / 24 / 32 / 48 / 56 / 64 lanes give 4.7 / 5.4 / 6.3 / 7.1 / 8.5 / 8.2 / 5.2e9
 // photon-steps/s f64 (profiles/r02e_large_mesh_query_threshold.log).  LT_QUERY_MIN in the environment overrides both.
 constexpr unsigned kQueryMinGlobal = 48;
+#ifndef LT_QUERY_MAX_AGE
+#define LT_QUERY_MAX_AGE 8
+#endif
+// ... but no lane waits longer than this many wave iterations: where queries are rare (a dense medium around a large mesh)
+// the lanes that wait would idle until enough of them have trickled in -- the 5140-triangle sphere in a medium of ten
+// times the scattering ran at 4.2e9 photon-steps/s without this bound and at 9.1-9.5e9 with 4 ... 10; C4 gains 1-5 % too
+// (profiles/r02e_large_mesh_query_threshold.log)
+constexpr unsigned kQueryMaxAge = LT_QUERY_MAX_AGE;
 
 // ---------------------------------------------------------------------------
 // the walk kernel

@@ -8,6 +8,8 @@ from tests import scenes as S
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2 * 10 ** 6
 prob = S.sphere_in_box(4, split_method=0)[0]
+if os.environ.get("LT_MESH_DENSE_MEDIA"):      # 10x the scattering: mean free path 0.02, surface queries become rare
+    prob.media = [(0.05, 50.0, 0.8, 1.0), (0.8, 80.0, 0.9, 1.37)]
 for env in ({}, {"LT_NO_NEAR_LISTS": "1"}, {"LT_NO_CLEARANCE": "1"}):
     os.environ.update(env)
     ctx = lt.Context(0)
