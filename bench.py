@@ -301,7 +301,9 @@ def main(argv=None):
                 continue
             cs = apply_regime(name)
             run_jobs(cs, len(cs), 900)                    # sizes the logs, pilot batch of a new scene
-            probe[name + "_ms"] = run_jobs(cs, 2 * len(cs), 910)
+            # 12 jobs per regime: enough that the pipeline's fill and drain (a third of a 6-job probe with three jobs in
+            # flight) no longer decide between regimes that differ by a millisecond per job
+            probe[name + "_ms"] = run_jobs(cs, max(12, 4 * len(cs)), 910)
         if distributed:     # every rank must take the same path: the collectives are issued per context in turn
             for k in sorted(probe):
                 t = dev.scalar(probe[k], torch.float64)
