@@ -941,10 +941,12 @@ def test_surface_query_shortcuts_do_not_change_results(ctx):
     """Mesh walks skip the BVH when the cell's clearance says no surface is within the hop, and test only the cell's
     listed nearest triangles when nothing else is (WalkParams::clear records): both are shortcuts, not approximations.
     u64 grids and step counts with the lists off (LT_NO_NEAR_LISTS=1), with the clearance grid off altogether
-    (LT_NO_CLEARANCE=1: every step queries the BVH) and with a coarse / a fine grid are identical bit for bit, on the
+    (LT_NO_CLEARANCE=1: every step queries the BVH), with a coarse / a fine grid, and with query services that wait for 1 or
+    for all 64 lanes are identical bit for bit, on the
     Cornell cavity + cone (30 triangles in LDS, area source) and on the 5140-triangle sphere (tables in global memory)."""
     cases = ((S.cornell(64), 200000), (S.sphere_in_box(4, split_method=0)[0], 60000))
-    variants = ({}, {"LT_NO_NEAR_LISTS": "1"}, {"LT_NO_CLEARANCE": "1"}, {"LT_CLEARANCE_CELLS": "16"}, {"LT_CLEARANCE_CELLS": "200"})
+    variants = ({}, {"LT_NO_NEAR_LISTS": "1"}, {"LT_NO_CLEARANCE": "1"}, {"LT_CLEARANCE_CELLS": "16"}, {"LT_CLEARANCE_CELLS": "200"},
+                {"LT_QUERY_MIN": "1"}, {"LT_QUERY_MIN": "64"})      # ... nor does the number of lanes a query service waits for
     for prob, n in cases:
         ref = None
         for env in variants:
