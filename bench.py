@@ -4,6 +4,7 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      (N > 1 without RANK in the environment: starts the line above as a child process)
 
 One "step" = one complete job on every rank: zero the tally, trace the workload's photons (f64 walk, XORWOW, f64 tally;
 deposits go through the log-structured tally: walk -> deposit log -> tile partition -> LDS reduce) and -- for N > 1 --
@@ -161,6 +162,23 @@ class HostDevice(Device):
         return np.empty(nbytes, dtype=np.uint8)
 
 
+def self_launch(n, argv):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <argv>` on a free local port
+    and return its exit code (stdout / stderr are inherited, so rank 0's JSON line is this command's JSON line)."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = str(s_.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL / dmabuf IPC on this pool's host driver
+    return subprocess.call(cmd, env=env)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,7 +215,11 @@ def main(argv=None):
     if args.gpus != world and distributed:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and not distributed:
-        raise SystemExit("for N > 1 launch through torch.distributed.run (one rank per GPU)")
+        # `python bench.py --gpus N` from a plain shell: become the launcher.  One rank per GPU is started through
+        # torch.distributed.run as a FRESH child process -- nothing in this process has touched the device (torch is not
+        # even imported yet) -- and this process only relays the child's exit code.  (Role of Numba's thread pool
+        # spreading render_scene's rows over the cores, S/path_tracing_fix1.py:139-148.)
+        sys.exit(self_launch(args.gpus, sys.argv[1:] if argv is None else list(argv)))
     fake = bool(args.ctx_factory)
     dev = HostDevice(local_rank) if fake else Device(local_rank)
     torch = dev.torch
@@ -209,15 +231,21 @@ def main(argv=None):
         else:
             dist.init_process_group(args.backend)
 
+    n_reduces = [0]
     if fake:
         mod, attr = args.ctx_factory.split(":")
         make_ctx = getattr(importlib.import_module(mod), attr)
-        reduce_ctx = lambda c: c.reduce_to(dist, 0)                              # noqa: E731
+        reduce_one = lambda c: c.reduce_to(dist, 0)                              # noqa: E731
     else:
         import light_transport_amd as lt
         from light_transport_amd import distributed as ltd
         make_ctx = lambda: lt.Context(local_rank)                                # noqa: E731
-        reduce_ctx = lambda c: ltd.reduce_device(c, dst=0)                       # RCCL sum of grid + counters to rank 0, on the ctx stream  # noqa: E731
+        # RCCL sum of grid + counters to rank 0, enqueued on the ctx stream; the host does not wait (finish() syncs the ctx)
+        reduce_one = lambda c: ltd.reduce_device(c, dst=0, wait=False)           # noqa: E731
+
+    def reduce_ctx(c):
+        n_reduces[0] += 1
+        reduce_one(c)
 
     offset = rank * per_gpu     # disjoint id ranges; streams depend on (seed, id) only
 
@@ -428,6 +456,7 @@ def main(argv=None):
                        "regime": regime, "jobs_in_flight": depth, "lanes_per_launch": lanes, "regime_probe": probe,
                        "parallelism": "photon-id sharding x%d, RCCL reduce of the grid to rank 0 per step, enqueued on the "
                                       "job's stream" % world if world > 1 else "single GPU",
+                       "reduce": {"backend": dist.get_backend() if distributed else None, "calls_rank0": n_reduces[0]},
                        "device": info["name"], "cus": info["cus"], "clock_mhz": info["clock_mhz"],
                        "hbm_gib": round(info["hbm_bytes"] / 2 ** 30, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

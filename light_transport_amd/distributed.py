@@ -45,15 +45,20 @@ def device_counter_tensors(ctx):
     return ints, flts
 
 
-def reduce_device(ctx, group=None, dst=None, wait=False):
+def reduce_device(ctx, group=None, dst=None, wait=True):
     """Sum-reduce grid and counters in place in HBM with torch.distributed (backend "nccl" == RCCL on ROCm),
     dst=None: all-reduce.  The collectives are issued with the ctx's own HIP stream as torch's current stream, so
-    they are ordered behind the launch that produced the grid and in front of whatever the caller enqueues on the
-    ctx next (counters readback, the next zero_tally) WITHOUT the host waiting for either: torch's NCCL process
-    group makes its communication stream wait for the current stream's work and, at ``Work.wait()``, the current
-    stream for the communication -- both are stream-level events.  Other contexts of the process keep running
-    meanwhile (two jobs in flight: one job's reduce travels over xGMI while the other job walks).
-    wait=True additionally blocks the host until this ctx's stream has drained."""
+    they are ordered behind the launch that produced the grid and in front of whatever the caller enqueues ON THE CTX
+    next (lt_read_grid, counters readback, the next zero_tally): torch's NCCL process group makes its communication
+    stream wait for the current stream's work and, at ``Work.wait()``, the current stream for the communication --
+    both are stream-level events.
+
+    wait=True (default): the host then blocks until the ctx stream has drained, so the reduced grid may be consumed
+    from ANY stream afterwards (``device_grid_tensor(ctx).cpu()`` on torch's default stream included).
+    wait=False: returns without a host or torch-stream sync -- the reduced grid may then only be consumed THROUGH THE
+    CTX (its stream: read_grid / read_counters / lt_stream) or after ``ctx.sync()``; a torch-side read on another
+    stream is NOT ordered behind the reduce.  bench.py uses this form so that, with several jobs in flight, one job's
+    reduce travels over xGMI while another job walks."""
     stream = torch.cuda.ExternalStream(ctx.stream(), device=torch.device("cuda", ctx.device_id))
     tensors = (device_grid_tensor(ctx),) + device_counter_tensors(ctx)
     with torch.cuda.stream(stream):

@@ -73,3 +73,24 @@ def test_bench_control_flow_world_size_2(tmp_path, regime, flags):
     assert len(timed_ctx) == depth
     # only rank 0 reads the grid back, after the timed region
     assert any(c["op"] == "read_grid_into" for c in calls[0]) and not any(c["op"] == "read_grid_into" for c in calls[1])
+
+
+def test_bench_self_launches_for_n_greater_than_1(tmp_path):
+    """`python3 bench.py --gpus 2` from a plain shell (no RANK in the environment -- the shape of the driver's N = 1
+    command): bench.py itself starts torch.distributed.run as a child and relays rank 0's JSON line and exit code."""
+    log = os.path.join(str(tmp_path), "calls")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LT_FAKE_LOG=log, PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--ctx-factory", "tests.fake_ctx:make",
+           "--no-cpu-baseline", "--inflight", "2", "--steps", "3", "--warmup", "1", "--photons", "1000"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["reduce"] == {"backend": "gloo", "calls_rank0": 4}
+    assert os.path.exists(log + ".0.jsonl") and os.path.exists(log + ".1.jsonl")      # two ranks really ran
+    # a failing child fails the launcher too
+    bad = subprocess.run([a if a != "tests.fake_ctx:make" else "tests.fake_ctx:no_such_factory" for a in cmd], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=240)
+    assert bad.returncode != 0 and "no_such_factory" in bad.stderr

@@ -95,3 +95,74 @@ def test_lt_reduce_grid_with_a_one_rank_rccl_communicator(ctx):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("flags", [["--workload", "c2", "--steps", "6"], ["--workload", "c5", "--steps", "2"]])
+def test_bench_self_launched_world_1_runs_reduce_device_on_rccl(flags):
+    """bench.py's own launcher (what `python bench.py --gpus N` does for N > 1) at world size 1: a fresh child under
+    torch.distributed.run, process group "nccl" (= RCCL), every job's grid + counters reduced by
+    distributed.reduce_device on the job's stream.  One JSON line, the regime probe ran, the reduces ran on RCCL."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    code = "import sys, bench; sys.exit(bench.self_launch(1, sys.argv[1:]))"
+    cmd = [sys.executable, "-c", code, "--gpus", "1", "--warmup", "1", "--no-cpu-baseline"] + flags
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    K = int(flags[-1])
+    assert out["n_gpus"] == 1 and out["steps"] == K and out["value"] > 1e10
+    probe = out["config"]["regime_probe"]
+    assert probe and probe["chosen"] == out["config"]["regime"] and "one_call_ms" in probe
+    red = out["config"]["reduce"]
+    assert red["backend"] == "nccl" and red["calls_rank0"] >= K + 1       # timed + warm-up (+ the probe's jobs)
+    assert out["roofline"]["frac"] > 0.02
+
+
+def _reduce_worker(rank, world, port, n_photons, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    import light_transport_amd as lt
+    from light_transport_amd.distributed import device_grid_tensor, reduce_device, shard_range
+    from tests import scenes as S
+    ctx = lt.Context(rank)
+    S.two_layer(n=64).apply(ctx, "u64fx")
+    off, cnt = shard_range(n_photons, rank, world)
+    ctx.launch(cnt, seed=77, photon_offset=off)
+    ctx.sync()
+    np.save(os.path.join(out_dir, "own%d.npy" % rank), ctx.read_grid_raw())
+    steps_own = ctx.read_counters()["steps"]
+    np.save(os.path.join(out_dir, "steps%d.npy" % rank), np.array([steps_own]))
+    reduce_device(ctx, dst=None)                       # default wait=True: consumable from any stream afterwards
+    red_torch = device_grid_tensor(ctx).cpu().numpy().view(np.uint64)     # torch's default stream
+    np.save(os.path.join(out_dir, "red%d.npy" % rank), ctx.read_grid_raw())
+    np.save(os.path.join(out_dir, "redt%d.npy" % rank), red_torch)
+    np.save(os.path.join(out_dir, "rsteps%d.npy" % rank), np.array([ctx.read_counters()["steps"]]))
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_device_two_ranks_rccl(tmp_path):
+    """The N > 1 device path proper (runs where the box has >= 2 GPUs): two ranks, one GPU each, RCCL all-reduce through
+    distributed.reduce_device.  The reduced fixed-point grid must equal the sum of the per-rank grids bit for bit, on the
+    ctx stream AND -- with the default wait=True -- when read through torch's default stream."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU node); world-size-1 RCCL and two-process gloo cover the rest")
+    n, d = 100001, str(tmp_path)
+    port = 29650 + (os.getpid() % 1500)
+    mp.spawn(_reduce_worker, args=(2, port, n, d), nprocs=2, join=True)
+    own = [np.load(os.path.join(d, "own%d.npy" % r)) for r in range(2)]
+    want = own[0] + own[1]
+    assert want.sum() > 0
+    steps = sum(int(np.load(os.path.join(d, "steps%d.npy" % r))[0]) for r in range(2))
+    for r in range(2):
+        assert np.array_equal(np.load(os.path.join(d, "red%d.npy" % r)), want)
+        assert np.array_equal(np.load(os.path.join(d, "redt%d.npy" % r)).reshape(want.shape), want)
+        assert int(np.load(os.path.join(d, "rsteps%d.npy" % r))[0]) == steps
