@@ -10,6 +10,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -117,6 +118,11 @@ struct lt_ctx {
     int cn[3] = {0, 0, 0};
     double corg[3] = {0, 0, 0}, ccell[3] = {1, 1, 1};
     bool have_clear = false;
+    // march grid (meshes whose f64 tables exceed the LDS budget): cell records, candidate lists, scratch of the builder
+    DevBuf d_mcell, d_mlist, d_mcoarse;
+    MarchGrid mgrid;
+    bool have_march = false;
+    size_t march_entries = 0;
     LogLane lanes[kMaxLanes];
     // hot-tile form of the two-pass partition (LogReduceParams::dmap): the map is made once per scene from the tile
     // counts a batch on lane 0 left behind (normally the pilot batch) and shared by every lane
@@ -230,6 +236,125 @@ int upload(lt_ctx* c, DevBuf& b, const std::vector<T>& h)
     return LT_OK;
 }
 
+// ---- march grid: which triangles touch which cell (host), exact triangle / box overlap -----------------------------
+// Separating-axis test of a triangle against an axis-aligned box (centre bc, half widths bh): the 3 box normals, the
+// triangle normal and the 9 cross products of edges and axes.  The box arrives already grown by the margin, so rounding in
+// here (1e-16 relative) cannot lose a triangle that really touches the cell.
+bool tri_box_overlap(const double bc[3], const double bh[3], const double* tri)
+{
+    double v[3][3];
+    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) v[i][k] = tri[3 * i + k] - bc[k];
+    for (int k = 0; k < 3; k++) {
+        const double lo = std::min(v[0][k], std::min(v[1][k], v[2][k])), hi = std::max(v[0][k], std::max(v[1][k], v[2][k]));
+        if (lo > bh[k] || hi < -bh[k]) return false;
+    }
+    const double e[3][3] = {{v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2]},
+                            {v[2][0] - v[1][0], v[2][1] - v[1][1], v[2][2] - v[1][2]},
+                            {v[0][0] - v[2][0], v[0][1] - v[2][1], v[0][2] - v[2][2]}};
+    for (int j = 0; j < 3; j++)          // axis = unit vector i x edge j
+        for (int i = 0; i < 3; i++) {
+            const int a = (i + 1) % 3, b = (i + 2) % 3;
+            const double ax = -e[j][b], bx = e[j][a];            // the axis has components (ax on a, bx on b)
+            const double p0 = ax * v[0][a] + bx * v[0][b], p1 = ax * v[1][a] + bx * v[1][b], p2 = ax * v[2][a] + bx * v[2][b];
+            const double r = bh[a] * std::fabs(ax) + bh[b] * std::fabs(bx);
+            if (std::min(p0, std::min(p1, p2)) > r || std::max(p0, std::max(p1, p2)) < -r) return false;
+        }
+    const double n[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2], e[0][0] * e[1][1] - e[0][1] * e[1][0]};
+    const double dn = n[0] * v[0][0] + n[1] * v[0][1] + n[2] * v[0][2];
+    const double r = bh[0] * std::fabs(n[0]) + bh[1] * std::fabs(n[1]) + bh[2] * std::fabs(n[2]);
+    return !(dn > r || dn < -r);
+}
+
+// Build the march grid of the ctx mesh: dimensions, candidate lists (host), clearances (device).
+int build_march_grid(lt_ctx* c)
+{
+    c->have_march = false;
+    const size_t nt = c->verts.size() / 9;
+    double ext[3], longest = 0;
+    for (int k = 0; k < 3; k++) { ext[k] = c->nodes[0].hi[k] - c->nodes[0].lo[k]; if (ext[k] > longest) longest = ext[k]; }
+    if (!(longest > 0) || !std::isfinite(longest) || nt == 0) return LT_OK;
+    // cell size ~ the median triangle's size (sqrt of twice its area): then a cell near the surface lists a handful of
+    // triangles and a hop of a few triangle sizes crosses a handful of cells.  32 .. 256 cells along the longest axis;
+    // LT_MARCH_CELLS=<n> pins the number, LT_MARCH_SCALE=<x> scales the cell size (tuning).
+    std::vector<double> size(nt);
+    for (size_t i = 0; i < nt; i++) {
+        const double* a = &c->verts[9 * i];
+        const double e1[3] = {a[3] - a[0], a[4] - a[1], a[5] - a[2]}, e2[3] = {a[6] - a[0], a[7] - a[1], a[8] - a[2]};
+        const double nn[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        size[i] = std::sqrt(std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]));
+    }
+    std::nth_element(size.begin(), size.begin() + nt / 2, size.end());
+    double h = size[nt / 2];
+    if (const char* e = std::getenv("LT_MARCH_SCALE")) { const double v = std::atof(e); if (v > 0.01 && v < 100) h *= v; }
+    int per_axis = h > 0 ? (int)std::lround(longest / h) : 256;
+    per_axis = per_axis < 32 ? 32 : (per_axis > 256 ? 256 : per_axis);
+    if (const char* e = std::getenv("LT_MARCH_CELLS")) { const int v = std::atoi(e); if (v >= 4 && v <= 512) per_axis = v; }
+    h = longest / (double)per_axis;
+    MarchGrid& G = c->mgrid;
+    int n[3];
+    for (int k = 0; k < 3; k++) {
+        n[k] = (int)std::ceil(ext[k] / h); if (n[k] < 1) n[k] = 1;
+        G.h[k] = ext[k] > 0 ? ext[k] / n[k] : h; G.org[k] = c->nodes[0].lo[k]; G.inv[k] = 1.0 / G.h[k];
+    }
+    G.nx = n[0]; G.ny = n[1]; G.nz = n[2];
+    const size_t cells = (size_t)n[0] * n[1] * n[2];
+    // margin by which a cell is grown before the overlap test: far above the rounding of the f32 walk's positions and hit
+    // parameters (1e-6 of the scene) and above the nudge by which the march steps past a cell wall, far below a cell
+    const double hmin = std::min(G.h[0], std::min(G.h[1], G.h[2]));
+    const double margin = std::max(1e-4 * hmin, 3e-5 * longest);
+    G.nudge64 = 1e-9 * hmin; G.nudge32 = 4e-6 * longest;      // (f32 positions carry ~1e-6 of the scene in rounding)
+    std::vector<uint32_t> count(cells, 0u);
+    std::vector<std::pair<uint32_t, uint32_t>> pairs;      // (cell, triangle), triangles ascending
+    pairs.reserve(nt * 8);
+    for (size_t i = 0; i < nt; i++) {
+        const double* a = &c->verts[9 * i];
+        int lo[3], hi[3];
+        for (int k = 0; k < 3; k++) {
+            const double mn = std::min(a[k], std::min(a[3 + k], a[6 + k])) - margin, mx = std::max(a[k], std::max(a[3 + k], a[6 + k])) + margin;
+            lo[k] = (int)std::floor((mn - G.org[k]) * G.inv[k]); hi[k] = (int)std::floor((mx - G.org[k]) * G.inv[k]);
+            lo[k] = lo[k] < 0 ? 0 : lo[k]; hi[k] = hi[k] >= n[k] ? n[k] - 1 : hi[k];
+        }
+        const double bh[3] = {0.5 * G.h[0] + margin, 0.5 * G.h[1] + margin, 0.5 * G.h[2] + margin};
+        for (int z = lo[2]; z <= hi[2]; z++)
+            for (int y = lo[1]; y <= hi[1]; y++)
+                for (int x = lo[0]; x <= hi[0]; x++) {
+                    const double bc[3] = {G.org[0] + (x + 0.5) * G.h[0], G.org[1] + (y + 0.5) * G.h[1], G.org[2] + (z + 0.5) * G.h[2]};
+                    if (!tri_box_overlap(bc, bh, a)) continue;
+                    const uint32_t ci = (uint32_t)(((size_t)z * n[1] + y) * n[0] + x);
+                    count[ci]++;
+                    pairs.emplace_back(ci, (uint32_t)i);
+                }
+    }
+    // record: candidate count in the low bits of x (the device adds c0 above them), start of the candidates in y
+    std::vector<uint2> rec(cells);
+    size_t total = 0;
+    for (size_t i = 0; i < cells; i++) {
+        rec[i].x = count[i] < kMarchCountMask ? count[i] : kMarchCountMask;      // 63: a long list -- that query walks the BVH
+        rec[i].y = (uint32_t)total;
+        total += count[i];
+    }
+    if (total >= (1u << 26)) return LT_OK;      // queue items address the list with 26 bits: such a mesh keeps the BVH walk (> ~5e6 triangles)
+    std::vector<uint32_t> list(total ? total : 1, 0u), fill(cells, 0u);
+    for (const auto& pr : pairs) list[rec[pr.first].y + fill[pr.first]++] = pr.second;
+    c->march_entries = pairs.size();
+    HIP_TRY(c, c->d_mcell.ensure(cells * sizeof(uint2)));
+    HIP_TRY(c, c->d_mlist.ensure(list.size() * 4));
+    const size_t nc = (size_t)((n[0] + 7) / 8) * ((n[1] + 7) / 8) * ((n[2] + 7) / 8);
+    HIP_TRY(c, c->d_mcoarse.ensure(nc * sizeof(double)));
+    HIP_TRY(c, hipMemcpyAsync(c->d_mcell.p, rec.data(), cells * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_mlist.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, c->stream));
+    G.cell = (const uint2*)c->d_mcell.p; G.list = (const uint32_t*)c->d_mlist.p;
+    HIP_TRY(c, launch_march_clearance(c->d_tris[0].p, c->d_nodes[0].p, (int)c->nodes.size(), G, (uint2*)c->d_mcell.p,
+                                      (double*)c->d_mcoarse.p, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // rec / list are pageable host memory
+    c->have_march = true;
+    if (std::getenv("LT_MARCH_INFO"))
+        std::fprintf(stderr, "[lt march] %zu triangles, grid %d x %d x %d (cell %.4g), %zu list entries (%.2f per triangle), %zu cells listed\n",
+                     nt, n[0], n[1], n[2], h, pairs.size(), (double)pairs.size() / (double)nt,
+                     (size_t)std::count_if(count.begin(), count.end(), [](uint32_t v) { return v != 0; }));
+    return LT_OK;
+}
+
 int upload_tables(lt_ctx* c)
 {
     if (!c->tables_dirty) return LT_OK;
@@ -257,9 +382,19 @@ int upload_tables(lt_ctx* c)
         if ((rc = upload(c, c->d_tris[1], t32))) return rc;
         if ((rc = upload(c, c->d_nodes[0], n64))) return rc;
         if ((rc = upload(c, c->d_nodes[1], n32))) return rc;
+        // Which acceleration data the walks of this mesh use: tables within the LDS budget -> clearance grid with
+        // near-triangle lists + BVH in LDS (GEOM 1); beyond it -> march grid (GEOM 2).  The f32 tables are about half the
+        // size of the f64 ones, so a mesh may need both.
+        Variant vq; std::memset(&vq, 0, sizeof vq); vq.mesh = 1;
+        const int nm = (int)c->media.size(), ntr = (int)t64.size(), nno = (int)n64.size();
+        const bool lds64 = walk_lds_bytes(vq, nm, 0, ntr, nno) <= kMeshLdsBudget;
+        vq.f32 = 1;
+        const bool lds32 = walk_lds_bytes(vq, nm, 0, ntr, nno) <= kMeshLdsBudget;
+        c->have_march = false;
+        if (!lds64 && !std::getenv("LT_NO_CLEARANCE") && !std::getenv("LT_NO_MARCH")) { if ((rc = build_march_grid(c))) return rc; }
         // clearance grid over the root bounds: 64 cells along the longest axis (LT_NO_CLEARANCE=1 disables it)
         c->have_clear = false;
-        if (!std::getenv("LT_NO_CLEARANCE")) {
+        if (!std::getenv("LT_NO_CLEARANCE") && (lds32 || !c->have_march)) {
             double ext[3], longest = 0;
             for (int k = 0; k < 3; k++) { ext[k] = c->nodes[0].hi[k] - c->nodes[0].lo[k]; if (ext[k] > longest) longest = ext[k]; }
             if (longest > 0 && std::isfinite(longest)) {
@@ -674,6 +809,7 @@ int lt_destroy(lt_ctx* c)
     c->d_mats.release(); c->d_lights.release(); c->d_r0.release(); c->d_r1.release(); c->d_lc.release();
     c->d_img.release(); c->d_xy.release(); c->d_vtx.release(); c->d_vcnt.release(); c->d_clear.release();
     c->d_job.release(); c->d_dmap.release(); c->d_dmeta.release();
+    c->d_mcell.release(); c->d_mlist.release(); c->d_mcoarse.release();
     for (int k = 1; k < kMaxLanes; k++) { c->d_gridx[k - 1].release(); if (c->lanes[k].stream) (void)hipStreamSynchronize(c->lanes[k].stream); }
     for (int k = 0; k < kMaxLanes; k++) {
         c->lanes[k].release_all();
@@ -876,6 +1012,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         P.clear = (const uint4*)c->d_clear.p; P.cnx = c->cn[0]; P.cny = c->cn[1]; P.cnz = c->cn[2];
         for (int k = 0; k < 3; k++) { P.corg[k] = c->corg[k]; P.cinv[k] = 1.0 / c->ccell[k]; }
     }
+    if (c->have_mesh && c->have_march) P.mg = c->mgrid;
     c->captured_photons = 0;
     if (c->max_vertices > 0) {
         const size_t vb = (size_t)n_photons * c->max_vertices * sizeof(lt_vertex);
@@ -893,7 +1030,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     if (v.mesh && cfg.lds_bytes > kMeshLdsBudget) {
         // large mesh: leave triangles and nodes in global memory (L2 / Infinity Cache resident)
         if (v.table) return c->fail(LT_E_UNSUPPORTED, "lt_launch: table RNG with a mesh beyond the LDS budget");
-        v.mesh = 2;
+        v.mesh = c->have_march ? 3 : 2;      // with a march grid: walk_kernel_m
         cfg.lds_bytes = walk_lds_bytes(v, P.n_media, P.n_layers, P.n_tris, P.n_nodes);
     }
     int resident = walk_max_blocks_per_cu(v, cfg.threads, cfg.lds_bytes);
@@ -1226,10 +1363,15 @@ int lt_intersect_rays(lt_ctx* c, const double* origins, const double* dirs, cons
     if (!c->have_mesh) return c->fail(LT_E_STATE, "lt_intersect_rays: lt_set_mesh first");
     if (n == 0) return LT_OK;
     if (!origins || !dirs || !prim_out || !t_out) return c->fail(LT_E_INVALID, "lt_intersect_rays: null argument");
+    if (use_bvh < 0 || use_bvh > 3) return c->fail(LT_E_INVALID, "lt_intersect_rays: use_bvh must be 0 (brute force), 1 (BVH), 2 (march grid, wave-cooperative) or 3 (march grid, lane by lane)");
     BIND(c);
     if (c->media.empty()) { lt_medium m = {0, 0, 0, 1}; c->media.push_back(m); }
     int rc = upload_tables(c);
     if (rc) return rc;
+    if (use_bvh >= 2 && !c->have_march) {      // small meshes have no march grid of their own: build one on request
+        if ((rc = build_march_grid(c))) return rc;
+        if (!c->have_march) return c->fail(LT_E_UNSUPPORTED, "lt_intersect_rays: no march grid for this mesh");
+    }
     // layout of the staging buffer: origins | dirs | tmax
     const size_t vb = n * 3 * sizeof(double), tb = n * sizeof(double);
     HIP_TRY(c, c->d_scratch_in.ensure(2 * vb + tb));
@@ -1241,7 +1383,7 @@ int lt_intersect_rays(lt_ctx* c, const double* origins, const double* dirs, cons
     HIP_TRY(c, c->d_scratch_aux.ensure(n * sizeof(int32_t)));
     HIP_TRY(c, launch_intersect_rays(c->d_tris[0].p, c->d_nodes[0].p, (int)c->med_front.size(), (int)c->nodes.size(),
                                      (const double*)base, (const double*)(base + vb),
-                                     tmax ? (const double*)(base + 2 * vb) : nullptr, n, use_bvh,
+                                     tmax ? (const double*)(base + 2 * vb) : nullptr, n, use_bvh, c->have_march ? &c->mgrid : nullptr,
                                      (int32_t*)c->d_scratch_aux.p, (double*)c->d_scratch_out.p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(prim_out, c->d_scratch_aux.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(t_out, c->d_scratch_out.p, tb, hipMemcpyDeviceToHost, c->stream));

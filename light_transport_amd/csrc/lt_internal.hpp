@@ -59,6 +59,23 @@ constexpr uint32_t kLogGroups = 16;
 constexpr uint32_t kLogGroups2 = 8;
 constexpr int kMaxLayers = 64;
 
+// March grid (meshes whose tables do not fit LDS, GEOM 2): a uniform grid over the root bounds of the BVH.  Every cell has
+// an 8-byte record -- x: c0 (f32 bits, rounded down to a multiple of 64 ulp), a strictly conservative lower bound of the
+// distance from ANY point of the cell to ANY triangle (a hop shorter than that cannot hit: no query at all), with the
+// number of the cell's candidates in the 6 low bits; y: where they start in `list` -- and the candidates are every
+// triangle that overlaps the cell grown by a margin (exact triangle / box separating-axis test on the host).  A query marches its hop segment through the
+// cells front to back (3-D DDA; free space is crossed c0 at a time) and tests the candidates of the cells it visits with the
+// walk's own tri_hit: same predicate, same nearest / tie rule, hence the same answer as a brute-force scan -- without a
+// per-lane pointer chase through a tree.  Role of intersect_bvh's near-child-first order (S/bvh_new.py:455-458).
+constexpr uint32_t kMarchCountMask = 63u;       // low bits of a cell record's x word: candidates of the cell (63: more than 62 -> that query walks the BVH)
+struct MarchGrid {
+    const uint2* cell;          // [nz][ny][nx]
+    const uint32_t* list;
+    int nx, ny, nz;
+    double org[3], inv[3], h[3];   // origin, 1 / cell size, cell size
+    double nudge64, nudge32;       // by how much the f64 / f32 march steps past a cell wall (<< the margin of the lists)
+};
+
 struct WalkParams {
     // photon queue
     unsigned long long* head;
@@ -105,6 +122,7 @@ struct WalkParams {
     const uint4* clear;
     int cnx, cny, cnz;
     double corg[3], cinv[3];
+    MarchGrid mg;         // GEOM 2 (cell == null: off -> every hop walks the BVH)
     // light sub-path capture (null = off)
     lt_vertex* vertices;
     uint32_t* vertex_counts;
@@ -119,7 +137,7 @@ struct LaunchCfg {
 // walk variants: precision x geometry x rng are compile-time, tally is too
 struct Variant {
     int f32;     // 0: f64 walk, 1: f32 walk
-    int mesh;    // 0: layered slab, 1: mesh + BVH staged in LDS, 2: mesh + BVH read from global memory
+    int mesh;    // 0: layered slab, 1: mesh + BVH staged in LDS, 2: mesh + BVH read from global memory, 3: the same with a march grid (walk_kernel_m)
     int table;   // 0: XORWOW, 1: table RNG
     int tally;   // LT_TALLY_*
     int capture; // 1: the build that stores light sub-path vertices (f64 walk, XORWOW)
@@ -148,6 +166,10 @@ struct RenderParams {
     int choices;   // variant 1: light_choice entries per sample
 };
 constexpr int kRenderOldMaxDepth = 24;   // frames of the unrolled recursion (variant 1)
+// march grid: exact point-to-mesh distance per cell by a pruned BVH nearest-point query, seeded from a coarse pass
+// (`coarse`: scratch of ceil(n/8)^3 doubles); fills the x word of every cell record
+hipError_t launch_march_clearance(const void* tris_f64, const void* nodes_f64, int n_nodes, const MarchGrid& G, uint2* cells,
+                                  double* coarse, hipStream_t s);
 hipError_t launch_build_clearance(const void* tris_f64, int n_tris, int near_lists, void* clear_records, int nx, int ny, int nz,
                                   const double org[3], const double cell[3], hipStream_t s);
 hipError_t launch_render_surface(const RenderParams& P, hipStream_t s);
@@ -210,9 +232,10 @@ hipError_t launch_log_part2(const LogReduceParams& L, hipStream_t s);
 hipError_t launch_log_reduce(const LogReduceParams& L, hipStream_t s);
 uint32_t log_part_item();   // records per partition work item (the log capacity is a multiple of it)
 
+// use_bvh: 0 brute force, 1 BVH, 2 march grid (G; falls back to the BVH for origins outside the grid)
 hipError_t launch_intersect_rays(const void* tris, const void* nodes, int n_tris, int n_nodes,
                                  const double* o, const double* d, const double* tmax, size_t n,
-                                 int use_bvh, int32_t* prim, double* t, hipStream_t s);
+                                 int use_bvh, const MarchGrid* G, int32_t* prim, double* t, hipStream_t s);
 hipError_t launch_triangle_intersect(const double* o, const double* d, const double* tris, size_t n,
                                      double* t, hipStream_t s);
 hipError_t launch_intersect_bounds(const double* o, const double* d, const double* tmax,

@@ -339,6 +339,277 @@ LT_DEV void nearest_listed(const TriD<R>* tris, const NodeD<R>* nodes, int n_nod
     }
 }
 
+// c0 of the cell that holds (px, py, pz): -1 outside the grid (always query)
+template <typename R> LT_DEV float march_clearance(const MarchGrid& G, R px, R py, R pz)
+{
+    const R cx = (px - (R)G.org[0]) * (R)G.inv[0], cy = (py - (R)G.org[1]) * (R)G.inv[1], cz = (pz - (R)G.org[2]) * (R)G.inv[2];
+    if (cx >= 0 && cx < (R)G.nx && cy >= 0 && cy < (R)G.ny && cz >= 0 && cz < (R)G.nz)
+        return __uint_as_float(G.cell[((size_t)(int)cz * G.ny + (int)cy) * G.nx + (int)cx].x & ~kMarchCountMask);
+    return -1.0f;
+}
+
+// Grid march (GEOM 2, MarchGrid in lt_internal.hpp): the hop segment o + t d, t in [t0, tmax), is walked cell by cell,
+// front to back -- the order the reference's traversal aims for by visiting the near child first (S/bvh_new.py:455-458).
+// Every visited cell's candidates are tested with consider() (= tri_hit + the nearest / tie rule), so the result equals
+// a brute-force scan:  a triangle hit at parameter t lies, up to rounding, in the cell the march is in at t, and the lists
+// hold every triangle within a margin (1e-5 of a cell, >= 1e4 x any rounding here) of the cell;  the march stops as soon as
+// the best hit so far is not beyond the exit of the current cell (everything nearer has been tested) or the segment ends.
+// Free space is crossed c0 at a time: no triangle lies within c0 of ANY point of a cell, the exit point included.
+// t0: a distance from o already known to be clear (the c0 of o's cell; 0 = none).
+// Origins outside the grid (open meshes) take the BVH.
+template <typename R>
+LT_DEV void nearest_march(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes, const MarchGrid& G, const R* o,
+                          const R* d, R tmax, R t0, int& prim, R& t_out)
+{
+    const R inf = Mx<R>::inf();
+    const R gx = (R)G.org[0], gy = (R)G.org[1], gz = (R)G.org[2];
+    const R ix_ = (R)G.inv[0], iy_ = (R)G.inv[1], iz_ = (R)G.inv[2];
+    const R hx = (R)G.h[0], hy = (R)G.h[1], hz = (R)G.h[2];
+    const R fnx = (R)G.nx, fny = (R)G.ny, fnz = (R)G.nz;
+    const R tol = (R)1e-4;                       // in cells: positions this close outside the grid are clamped into it
+    {
+        const R fx = (o[0] - gx) * ix_, fy = (o[1] - gy) * iy_, fz = (o[2] - gz) * iz_;
+        if (!(fx >= -tol && fx <= fnx + tol && fy >= -tol && fy <= fny + tol && fz >= -tol && fz <= fnz + tol)) {
+            nearest_bvh(tris, nodes, n_nodes, o, d, tmax, prim, t_out);
+            return;
+        }
+    }
+    int bi = -1; R bt = tmax;
+    // an axis the ray does not move along never steps (1 / d would be +-inf, 0 * inf a NaN)
+    const R tiny = sizeof(R) == 8 ? (R)1e-200 : (R)1e-30;
+    const bool mx = Mx<R>::abs(d[0]) > tiny, my = Mx<R>::abs(d[1]) > tiny, mz = Mx<R>::abs(d[2]) > tiny;
+    const R idx_ = mx ? (R)1 / d[0] : inf, idy_ = my ? (R)1 / d[1] : inf, idz_ = mz ? (R)1 / d[2] : inf;
+    const R tdx = mx ? hx * Mx<R>::abs(idx_) : inf, tdy = my ? hy * Mx<R>::abs(idy_) : inf, tdz = mz ? hz * Mx<R>::abs(idz_) : inf;
+    const int sx = d[0] > 0 ? 1 : -1, sy = d[1] > 0 ? 1 : -1, sz = d[2] > 0 ? 1 : -1;
+    int cx = 0, cy = 0, cz = 0;
+    R tmx = inf, tmy = inf, tmz = inf;
+    R t = t0 > 0 ? t0 : (R)0;
+    bool inside = true;
+    // (re)start the DDA at parameter t: cell of the point, parameter of the next cell wall on every axis
+    auto restart = [&]() {
+        const R fx = (o[0] + t * d[0] - gx) * ix_, fy = (o[1] + t * d[1] - gy) * iy_, fz = (o[2] + t * d[2] - gz) * iz_;
+        inside = fx >= -tol && fx <= fnx + tol && fy >= -tol && fy <= fny + tol && fz >= -tol && fz <= fnz + tol;
+        cx = (int)__builtin_floor(fx); cy = (int)__builtin_floor(fy); cz = (int)__builtin_floor(fz);
+        cx = cx < 0 ? 0 : (cx >= G.nx ? G.nx - 1 : cx);
+        cy = cy < 0 ? 0 : (cy >= G.ny ? G.ny - 1 : cy);
+        cz = cz < 0 ? 0 : (cz >= G.nz ? G.nz - 1 : cz);
+        tmx = mx ? (gx + (R)(cx + (sx > 0 ? 1 : 0)) * hx - o[0]) * idx_ : inf;
+        tmy = my ? (gy + (R)(cy + (sy > 0 ? 1 : 0)) * hy - o[1]) * idy_ : inf;
+        tmz = mz ? (gz + (R)(cz + (sz > 0 ? 1 : 0)) * hz - o[2]) * idz_ : inf;
+    };
+    if (!(t < bt)) { prim = -1; t_out = inf; return; }
+    restart();
+    const R jump_min = (R)1.5 * (hx < hy ? (hx < hz ? hx : hz) : (hy < hz ? hy : hz));   // a jump must beat a DDA step
+    while (inside) {
+        const uint2 rec = G.cell[((size_t)cz * G.ny + cy) * G.nx + cx];
+        const R tex = tmx < tmy ? (tmx < tmz ? tmx : tmz) : (tmy < tmz ? tmy : tmz);
+        const unsigned n = rec.x & kMarchCountMask;
+        if (n == kMarchCountMask) { nearest_bvh(tris, nodes, n_nodes, o, d, tmax, prim, t_out); return; }   // a cell with a long list
+        const uint32_t* L = G.list + rec.y;
+        for (unsigned k = 0; k < n; k++) consider(tris, (int)L[k], o, d, bi, bt);
+        if (!(tex < bt)) break;          // the segment (or everything nearer than the best hit) ends inside this cell
+        const R clr = (R)__uint_as_float(rec.x & ~kMarchCountMask);
+        if (clr > jump_min) {
+            t = tex + clr;
+            if (!(t < bt)) break;
+            restart();
+        } else if (tmx <= tmy && tmx <= tmz) { cx += sx; tmx += tdx; inside = cx >= 0 && cx < G.nx; }
+        else if (tmy <= tmz) { cy += sy; tmy += tdy; inside = cy >= 0 && cy < G.ny; }
+        else { cz += sz; tmz += tdz; inside = cz >= 0 && cz < G.nz; }
+    }
+    prim = bi; t_out = bi >= 0 ? bt : inf;
+}
+
+// The walk's form of the grid march: the lanes of a wave that need a surface query are served TOGETHER.
+// Marching lane by lane (nearest_march) is a chain of dependent loads per lane -- cell record, candidate id, triangle --
+// and the wave pays for its longest lane: instrumented on the reference's teapot, the average lane tested 2.4 triangles,
+// the longest 19, at ~3000 cycles per link of the chain (96 000 cycles per service, 67 % of the walk).  Here the lanes only
+// march (march_round: one cell per lane per round, candidates pushed as (lane, list position) items into a queue in LDS)
+// and the WHOLE wave tests the queued (ray, triangle) pairs, one pair per lane per round, whoever's they are
+// (march_drain): the triangle tests run on full waves with independent loads, and the nearest hit of every ray is folded
+// with LDS atomics -- min over the bit patterns of t (positive floats order like unsigned integers), then min over the
+// ids of the triangles that reach that t: the nearest / tie rule of consider().  A ray's candidates are the triangles of
+// the cells its segment crosses up to the best hit known when a cell is entered; tests beyond the nearest hit cannot
+// change it, so the answer is the brute-force scan's.
+// The march is position based: a round computes the cell of the point at parameter tcur, and tcur then moves to the
+// cell's exit plus a nudge (far above rounding, far below the margin the candidate lists were built with, so whatever
+// the nudge skips is listed in the cell just left) -- or past the exit by the cell's clearance.  Only tcur lives in a
+// register between rounds, which lets the walk run rounds as part of its own iterations (lt_walk_kernel.inc, batch 2).
+constexpr unsigned kMarchQ = 256;               // queue items per wave: four rounds of march_drain
+constexpr unsigned kMarchNone = 0xffffffffu;
+template <typename R> struct MarchBits { typedef unsigned long long type; };
+template <> struct MarchBits<float> { typedef unsigned type; };
+template <typename R> struct MarchWave {        // per wave, in LDS
+    typename MarchBits<R>::type slot_t[64];     // best t per ray (bits), starts at the ray's tmax
+    unsigned slot_i[64];                        // triangle of that t (lowest id on ties)
+    R ray[9][64];                               // origin, direction, 1 / direction (inf for an axis the ray does not move along)
+    unsigned q_item[kMarchQ];                   // lane << 26 | position in MarchGrid::list
+    typename MarchBits<R>::type q_t[kMarchQ];   // t of the item's test (all ones: no hit)
+};
+LT_DEV unsigned long long march_bits(double t) { return (unsigned long long)__double_as_longlong(t); }
+LT_DEV unsigned march_bits(float t) { return __float_as_uint(t); }
+LT_DEV double march_unbits(unsigned long long b) { return __longlong_as_double((long long)b); }
+LT_DEV float march_unbits(unsigned b) { return __uint_as_float(b); }
+
+// a lane's query enters the march: ray and best-hit slot into LDS.  false: the origin lies outside the grid (open meshes)
+// -- that query takes the BVH.
+template <typename R>
+LT_DEV bool march_enter(const MarchGrid& G, MarchWave<R>* W, R px, R py, R pz, R ux, R uy, R uz, R tmax)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const R inf = Mx<R>::inf(), tiny = sizeof(R) == 8 ? (R)1e-200 : (R)1e-30, tol = (R)1e-4;
+    W->ray[0][lane] = px; W->ray[1][lane] = py; W->ray[2][lane] = pz;
+    W->ray[3][lane] = ux; W->ray[4][lane] = uy; W->ray[5][lane] = uz;
+    W->ray[6][lane] = Mx<R>::abs(ux) > tiny ? (R)1 / ux : inf;
+    W->ray[7][lane] = Mx<R>::abs(uy) > tiny ? (R)1 / uy : inf;
+    W->ray[8][lane] = Mx<R>::abs(uz) > tiny ? (R)1 / uz : inf;
+    W->slot_t[lane] = march_bits(tmax); W->slot_i[lane] = kMarchNone;
+    const R fx = (px - (R)G.org[0]) * (R)G.inv[0], fy = (py - (R)G.org[1]) * (R)G.inv[1], fz = (pz - (R)G.org[2]) * (R)G.inv[2];
+    return fx >= -tol && fx <= (R)G.nx + tol && fy >= -tol && fy <= (R)G.ny + tol && fz >= -tol && fz <= (R)G.nz + tol;
+}
+
+// One round: every marching lane visits the cell of its point at tcur, queues the cell's candidates and moves tcur on.
+// marching goes false when the segment (or everything nearer than the best hit) ends, or the ray leaves the grid;
+// heavy: the cell has a long list (that query takes the BVH); dirty: the lane has items in the queue; qn: items in the
+// queue (wave-uniform); returns true when some lane could not queue its candidates (it stays on its cell: drain, then go on).
+template <typename R>
+LT_DEV bool march_round(const MarchGrid& G, MarchWave<R>* W, bool& marching, bool& heavy, bool& dirty, R& tcur, unsigned& qn)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const R inf = Mx<R>::inf(), tol = (R)1e-4;
+    const R hx = (R)G.h[0], hy = (R)G.h[1], hz = (R)G.h[2];
+    const R nudge = sizeof(R) == 8 ? (R)G.nudge64 : (R)G.nudge32;
+    unsigned n = 0, lst = 0;
+    R tex = inf, bt = inf; float clr = 0.0f;
+    bool m = marching;
+    if (m) {
+        bt = march_unbits(W->slot_t[lane]);
+        if (!(tcur < bt)) m = false;
+    }
+    if (m) {
+        const R px = W->ray[0][lane], py = W->ray[1][lane], pz = W->ray[2][lane];
+        const R ux = W->ray[3][lane], uy = W->ray[4][lane], uz = W->ray[5][lane];
+        const R fx = (px + tcur * ux - (R)G.org[0]) * (R)G.inv[0], fy = (py + tcur * uy - (R)G.org[1]) * (R)G.inv[1],
+                fz = (pz + tcur * uz - (R)G.org[2]) * (R)G.inv[2];
+        // out of the grid, or on its outer wall and heading out: nothing beyond the root bounds (the walls themselves are
+        // listed in the outermost cells, which the march has visited by then)
+        if (!(fx >= -tol && fx <= (R)G.nx + tol && fy >= -tol && fy <= (R)G.ny + tol && fz >= -tol && fz <= (R)G.nz + tol) ||
+            (ux > 0 ? fx >= (R)G.nx : (ux < 0 && fx <= 0)) || (uy > 0 ? fy >= (R)G.ny : (uy < 0 && fy <= 0)) ||
+            (uz > 0 ? fz >= (R)G.nz : (uz < 0 && fz <= 0))) m = false;
+        else {
+            int cx = (int)__builtin_floor(fx), cy = (int)__builtin_floor(fy), cz = (int)__builtin_floor(fz);
+            cx = cx < 0 ? 0 : (cx >= G.nx ? G.nx - 1 : cx);
+            cy = cy < 0 ? 0 : (cy >= G.ny ? G.ny - 1 : cy);
+            cz = cz < 0 ? 0 : (cz >= G.nz ? G.nz - 1 : cz);
+            const uint2 rec = G.cell[((size_t)cz * G.ny + cy) * G.nx + cx];
+            n = rec.x & kMarchCountMask; lst = rec.y; clr = __uint_as_float(rec.x & ~kMarchCountMask);
+            if (n == kMarchCountMask) { heavy = true; m = false; n = 0; }
+            // parameter at which the ray leaves this cell (inf on an axis it does not move along: 1 / d is inf there and the
+            // numerator is never 0 * inf because it is taken as inf outright)
+            const R ix = W->ray[6][lane], iy = W->ray[7][lane], iz = W->ray[8][lane];
+            const R ex = ix < inf && ix > -inf ? ((R)G.org[0] + (R)(cx + (ux > 0 ? 1 : 0)) * hx - px) * ix : inf;
+            const R ey = iy < inf && iy > -inf ? ((R)G.org[1] + (R)(cy + (uy > 0 ? 1 : 0)) * hy - py) * iy : inf;
+            const R ez = iz < inf && iz > -inf ? ((R)G.org[2] + (R)(cz + (uz > 0 ? 1 : 0)) * hz - pz) * iz : inf;
+            tex = ex < ey ? (ex < ez ? ex : ez) : (ey < ez ? ey : ez);
+        }
+    }
+    if (!m) marching = false;
+    unsigned incl = n;                    // inclusive prefix sum of n over the lanes
+#pragma unroll
+    for (unsigned off = 1; off < 64; off <<= 1) { const unsigned v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    const unsigned excl = incl - n, cap = kMarchQ - qn;
+    const bool blocked = incl > cap;                            // does not fit: the lane stays on this cell until the queue has drained
+    const unsigned long long bm = __ballot(blocked);            // (the blocked lanes are a suffix: the prefix sums ascend)
+    const unsigned pushed = bm ? (unsigned)__shfl(excl, __ffsll((long long)bm) - 1, 64) : (unsigned)__shfl(incl, 63, 64);
+    if (!blocked) for (unsigned k = 0; k < n; k++) W->q_item[qn + excl + k] = (lane << 26) | (lst + k);
+    qn += pushed;
+    if (m && !blocked) {
+        if (n) dirty = true;
+        const R jump_min = (R)1.5 * (hx < hy ? (hx < hz ? hx : hz) : (hy < hz ? hy : hz));
+        if (!(tex < bt)) marching = false;          // the segment (or everything nearer than the best hit) ends in this cell
+        else {
+            // free space: no triangle lies within clr of ANY point of this cell, its exit point included
+            R tn = (R)clr > jump_min ? tex + (R)clr : tex + nudge;
+            const R floor_ = tcur + nudge;          // (a round always moves on, whatever rounding did to tex)
+            tcur = tn > floor_ ? tn : floor_;
+            if (!(tcur < bt)) marching = false;
+        }
+    }
+    return bm != 0ull;
+}
+
+// The wave tests the queued pairs, one per lane per round, and folds the hits into the rays' slots.
+template <typename R>
+LT_DEV void march_drain(const TriD<R>* tris, const MarchGrid& G, MarchWave<R>* W, unsigned& qn)
+{
+    typedef typename MarchBits<R>::type UB;
+    const unsigned lane = threadIdx.x & 63u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (unsigned j0 = 0; j0 < qn; j0 += 64u) {
+        const unsigned j = j0 + lane;
+        UB tb = ~(UB)0;
+        if (j < qn) {
+            const unsigned item = W->q_item[j], src = item >> 26;
+            const int id = (int)G.list[item & 0x3ffffffu];
+            const R o[3] = {W->ray[0][src], W->ray[1][src], W->ray[2][src]};
+            const R d[3] = {W->ray[3][src], W->ray[4][src], W->ray[5][src]};
+            const R t = tri_hit(o, d, &tris[id]);
+            if (t == t && t > (R)1e-6) {        // consider(): EPSILON < t; "< best" is the atomic min itself
+                tb = march_bits(t);
+                const UB old = __hip_atomic_fetch_min(&W->slot_t[src], tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (tb < old) W->slot_i[src] = kMarchNone;      // a nearer hit: the ids collected for the old t are void
+            }
+        }
+        W->q_t[j] = tb;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (unsigned j0 = 0; j0 < qn; j0 += 64u) {
+        const unsigned j = j0 + lane;
+        if (j < qn) {
+            const UB tb = W->q_t[j];
+            const unsigned item = W->q_item[j], src = item >> 26;
+            if (tb != ~(UB)0 && tb == W->slot_t[src])
+                (void)__hip_atomic_fetch_min(&W->slot_i[src], G.list[item & 0x3ffffffu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    qn = 0;
+}
+
+// a finished query's answer (the lane's slot, or the BVH for the queries the grid could not take)
+template <typename R>
+LT_DEV void march_result(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes, MarchWave<R>* W, bool use_bvh, R px, R py, R pz,
+                         R ux, R uy, R uz, R tmax, int& prim, R& t_out)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    prim = -1; t_out = Mx<R>::inf();
+    if (use_bvh) {
+        const R o[3] = {px, py, pz}, d[3] = {ux, uy, uz};
+        nearest_bvh(tris, nodes, n_nodes, o, d, tmax, prim, t_out);
+    } else {
+        const typename MarchBits<R>::type b = W->slot_t[lane];
+        if (b < march_bits(tmax)) { prim = (int)W->slot_i[lane]; t_out = march_unbits(b); }
+    }
+}
+
+// all of it for one batch of rays (one per lane; want: this lane has a ray): rounds until every ray is answered
+template <typename R>
+LT_DEV void march_service(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes, const MarchGrid& G, MarchWave<R>* W,
+                          bool want, R px, R py, R pz, R ux, R uy, R uz, R tmax, R t0, int& prim, R& t_out)
+{
+    bool marching = false, heavy = false, dirty = false, outside = false;
+    R tcur = t0 > 0 ? t0 : (R)0;
+    if (want) { outside = !march_enter(G, W, px, py, pz, ux, uy, uz, tmax); marching = !outside; }
+    unsigned qn = 0;
+    while (__any(marching) || qn > 0) {
+        bool full = false;
+        if (__any(marching)) full = march_round(G, W, marching, heavy, dirty, tcur, qn);
+        if (qn > 0 && (full || qn >= 64u || !__any(marching))) march_drain(tris, G, W, qn);
+    }
+    if (want) march_result(tris, nodes, n_nodes, W, outside || heavy, px, py, pz, ux, uy, uz, tmax, prim, t_out);
+    else { prim = -1; t_out = Mx<R>::inf(); }
+}
+
 // ---------------------------------------------------------------------------
 // sampling
 // ---------------------------------------------------------------------------
@@ -522,8 +793,8 @@ template <int TALLY> LT_DEV void tally_add(void* grid, unsigned idx, typename Ta
 LT_DEV size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 template <typename R> struct LdsLayout {
-    size_t off_cnt, off_media, off_zb, off_lm, off_tris, off_nodes, off_hist, total;
-    __host__ __device__ LdsLayout(int n_media, int n_layers, int n_tris, int n_nodes, unsigned n_hist = 0)
+    size_t off_cnt, off_media, off_zb, off_lm, off_tris, off_nodes, off_hist, off_march, total;
+    __host__ __device__ LdsLayout(int n_media, int n_layers, int n_tris, int n_nodes, unsigned n_hist = 0, size_t march_bytes = 0)
     {
         auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
         size_t o = 0;
@@ -534,6 +805,7 @@ template <typename R> struct LdsLayout {
         off_tris = o;  o = al(o + (size_t)n_tris * sizeof(TriD<R>));
         off_nodes = o; o = al(o + (size_t)n_nodes * sizeof(NodeD<R>));
         off_hist = o;  o = al(o + (size_t)n_hist * sizeof(uint32_t));
+        off_march = o; o = al(o + march_bytes);
         total = o;
     }
 };
@@ -648,6 +920,12 @@ constexpr unsigned kQueryMinGlobal = 48;
 // times the scattering ran at 4.2e9 photon-steps/s without this bound and at 9.1-9.5e9 with 4 ... 10; C4 gains 1-5 % too
 // (profiles/r02e_large_mesh_query_threshold.log)
 constexpr unsigned kQueryMaxAge = LT_QUERY_MAX_AGE;
+#ifndef LT_MARCH_DRAIN_MIN
+#define LT_MARCH_DRAIN_MIN 8
+#endif
+// walk_kernel_m: queries whose march has ended and that only wait for their queued candidates to be tested; this many
+// trigger a drain of a queue that holds less than a full round (LT_QUERY_MIN in the environment overrides)
+constexpr unsigned kMarchDrainMin = LT_MARCH_DRAIN_MIN;
 
 // ---------------------------------------------------------------------------
 // the walk kernel
@@ -656,6 +934,9 @@ constexpr unsigned kQueryMaxAge = LT_QUERY_MAX_AGE;
 // dependent f64 / transcendental chains once deposition no longer paces the walk)
 #ifndef LT_F64_WAVES
 #define LT_F64_WAVES 4        // f64 mesh walks: ~80 B of scratch per lane at 128 VGPRs, still 6 % faster than 3 waves (C4)
+#endif
+#ifndef LT_F64_GLOBAL_WAVES
+#define LT_F64_GLOBAL_WAVES 3 // f64 walks of meshes beyond LDS (grid march): the DDA state on top of the photon's does not fit 128 VGPRs
 #endif
 #ifndef LT_F64_SLAB_WAVES
 #define LT_F64_SLAB_WAVES 4   // f64 slab walks fit 128 VGPRs without scratch since the polynomial constants live in SGPRs
@@ -670,6 +951,11 @@ constexpr unsigned kQueryMaxAge = LT_QUERY_MAX_AGE;
 #undef LT_WALK_BATCH
 #define LT_WALK_NAME walk_kernel_q
 #define LT_WALK_BATCH 1
+#include "lt_walk_kernel.inc"
+#undef LT_WALK_NAME
+#undef LT_WALK_BATCH
+#define LT_WALK_NAME walk_kernel_m
+#define LT_WALK_BATCH 2
 #include "lt_walk_kernel.inc"
 #undef LT_WALK_NAME
 #undef LT_WALK_BATCH
@@ -703,9 +989,22 @@ static WalkFn pick_tally(int tally)
     return nullptr;
 }
 
+// meshes beyond LDS with a march grid (Variant::mesh 3): walk_kernel_m, tables in global memory (GEOM 2)
+template <typename R, bool CAPTURE>
+static WalkFn pick_march(int tally)
+{
+    switch (tally) {
+    case LT_TALLY_F32: return walk_kernel_m<R, 2, false, LT_TALLY_F32, CAPTURE>;
+    case LT_TALLY_F64: return walk_kernel_m<R, 2, false, LT_TALLY_F64, CAPTURE>;
+    case LT_TALLY_U64FX: return walk_kernel_m<R, 2, false, LT_TALLY_U64FX, CAPTURE>;
+    }
+    return nullptr;
+}
+
 template <typename R, bool TABLE, bool CAPTURE>
 static WalkFn pick_geom(const Variant& v)
 {
+    if (v.mesh == 3) { if constexpr (!TABLE) return pick_march<R, CAPTURE>(v.tally); else return nullptr; }
     if (v.mesh == 0) return pick_tally<R, 0, TABLE, CAPTURE>(v.tally);
     if (v.mesh == 1) return pick_tally<R, 1, TABLE, CAPTURE>(v.tally);
     if constexpr (!TABLE) return pick_tally<R, 2, TABLE, CAPTURE>(v.tally); else return nullptr;
@@ -722,8 +1021,9 @@ size_t walk_lds_bytes(const Variant& v, int n_media, int n_layers, int n_tris, i
 {
     if (v.mesh) n_layers = 0;
     if (v.mesh != 1) { n_tris = 0; n_nodes = 0; }
-    return v.f32 ? LdsLayout<float>(n_media, n_layers, n_tris, n_nodes, n_hist).total
-                 : LdsLayout<double>(n_media, n_layers, n_tris, n_nodes, n_hist).total;
+    // GEOM 2: the march service's per-wave scratch (rays, best hits, candidate queue), four waves per workgroup
+    return v.f32 ? LdsLayout<float>(n_media, n_layers, n_tris, n_nodes, n_hist, v.mesh >= 2 ? 4 * sizeof(MarchWave<float>) : 0).total
+                 : LdsLayout<double>(n_media, n_layers, n_tris, n_nodes, n_hist, v.mesh >= 2 ? 4 * sizeof(MarchWave<double>) : 0).total;
 }
 
 int walk_max_blocks_per_cu(const Variant& v, int threads, size_t lds_bytes)
@@ -756,14 +1056,25 @@ hipError_t launch_walk(const WalkParams& Pin, const Variant& v, const LaunchCfg&
 // ---------------------------------------------------------------------------
 __global__ void k_intersect_rays(const TriD<double>* tris, const NodeD<double>* nodes, int n_tris, int n_nodes,
                                  const double* o, const double* d, const double* tmax, size_t n, int use_bvh,
-                                 int32_t* prim, double* t)
+                                 const MarchGrid G, int32_t* prim, double* t)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (use_bvh == 2) {     // the walk's wave-cooperative march (256 threads per workgroup: four waves)
+        __shared__ MarchWave<double> mw[4];
+        const bool want = i < n;
+        const size_t k = want ? i : 0;
+        int pi; double tt;
+        march_service<double>(tris, nodes, n_nodes, G, &mw[threadIdx.x >> 6], want, o[3 * k], o[3 * k + 1], o[3 * k + 2], d[3 * k], d[3 * k + 1],
+                              d[3 * k + 2], tmax ? tmax[k] : __builtin_huge_val(), 0.0, pi, tt);
+        if (want) { prim[i] = pi; t[i] = tt; }
+        return;
+    }
     if (i >= n) return;
     double oo[3] = {o[3 * i], o[3 * i + 1], o[3 * i + 2]}, dd[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
     double tm = tmax ? tmax[i] : __builtin_huge_val();
     int pi; double tt;
-    if (use_bvh) nearest_bvh(tris, nodes, n_nodes, oo, dd, tm, pi, tt);
+    if (use_bvh == 3) nearest_march(tris, nodes, n_nodes, G, oo, dd, tm, 0.0, pi, tt);      // the same march, lane by lane
+    else if (use_bvh) nearest_bvh(tris, nodes, n_nodes, oo, dd, tm, pi, tt);
     else nearest_brute(tris, n_tris, oo, dd, tm, pi, tt);
     prim[i] = pi; t[i] = tt;
 }
@@ -974,6 +1285,80 @@ hipError_t launch_build_clearance(const void* tris_f64, int n_tris, int near_lis
     hipLaunchKernelGGL(k_build_clearance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const TriD<double>*>(tris_f64), n_tris, near_lists, reinterpret_cast<uint4*>(clear_records), nx, ny, nz,
                        org[0], org[1], org[2], cell[0], cell[1], cell[2]);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// march grid: c0 of every cell from the EXACT distance of the cell centre to the mesh, found by a nearest-point query in
+// the BVH (a subtree is skipped when its box is not nearer than the best triangle so far).  Two levels: a coarse grid
+// (cells 8 x 8 x 8 fine cells wide) is searched without a bound; a fine cell then starts from the bound its coarse cell
+// implies, dist(p) <= dist(q) + |p - q|, so its search only opens the few subtrees around that sphere.  Cost ~ cells x
+// tens of nodes instead of cells x triangles (k_build_clearance): 10^4 triangles get 128^3 cells instead of 58^3.
+// ---------------------------------------------------------------------------
+LT_DEV double point_box_dist2(const double* p, const NodeD<double>& nd)
+{
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double e = __builtin_fmax(__builtin_fmax(nd.lo[k] - p[k], p[k] - nd.hi[k]), 0.0);
+        s += e * e;
+    }
+    return s;
+}
+LT_DEV double mesh_dist2(const TriD<double>* tris, const NodeD<double>* nodes, int n_nodes, const double* p, double best)
+{
+    int cur = 0;
+    while (cur < n_nodes) {
+        const NodeD<double>& nd = nodes[cur];
+        if (point_box_dist2(p, nd) <= best) {
+            if (nd.n_prims > 0) {
+                for (int k = 0; k < nd.n_prims; k++) best = __builtin_fmin(best, point_tri_dist2(p, tris[nd.offset + k]));
+                cur = nd.skip;
+            } else cur++;
+        } else cur = nd.skip;
+    }
+    return best;
+}
+__global__ void k_march_coarse(const TriD<double>* tris, const NodeD<double>* nodes, int n_nodes, const MarchGrid G, int kx, int ky,
+                               int kz, double* coarse)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)kx * ky * kz) return;
+    const int ix = (int)(i % kx), iy = (int)((i / kx) % ky), iz = (int)(i / ((size_t)kx * ky));
+    const double p[3] = {G.org[0] + (ix + 0.5) * 8.0 * G.h[0], G.org[1] + (iy + 0.5) * 8.0 * G.h[1], G.org[2] + (iz + 0.5) * 8.0 * G.h[2]};
+    coarse[i] = ::sqrt(mesh_dist2(tris, nodes, n_nodes, p, __builtin_huge_val()));
+}
+__global__ void k_march_fine(const TriD<double>* tris, const NodeD<double>* nodes, int n_nodes, const MarchGrid G, int kx, int ky,
+                             const double* coarse, uint2* cells)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)G.nx * G.ny * G.nz) return;
+    const int ix = (int)(i % G.nx), iy = (int)((i / G.nx) % G.ny), iz = (int)(i / ((size_t)G.nx * G.ny));
+    const double p[3] = {G.org[0] + (ix + 0.5) * G.h[0], G.org[1] + (iy + 0.5) * G.h[1], G.org[2] + (iz + 0.5) * G.h[2]};
+    const int qx = ix >> 3, qy = iy >> 3, qz = iz >> 3;
+    const double q[3] = {G.org[0] + (qx + 0.5) * 8.0 * G.h[0], G.org[1] + (qy + 0.5) * 8.0 * G.h[1], G.org[2] + (qz + 0.5) * 8.0 * G.h[2]};
+    const double e[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
+    const double up = (coarse[((size_t)qz * ky + qy) * kx + qx] + ::sqrt(dot3(e, e))) * (1.0 + 1e-9);     // dist(p) <= this
+    const double d2 = mesh_dist2(tris, nodes, n_nodes, p, up * up);
+    const double half_diag = 0.5 * ::sqrt(G.h[0] * G.h[0] + G.h[1] * G.h[1] + G.h[2] * G.h[2]);
+    // strictly conservative for every point of the cell (as k_build_clearance)
+    double c0 = (::sqrt(d2) - half_diag) * (1.0 - 1e-6) - 1e-7 * (G.h[0] + G.h[1] + G.h[2]);
+    if (!(c0 > 0)) c0 = 0.0;
+    float f = (float)c0;
+    if ((double)f > c0 && f > 0) f = __uint_as_float(__float_as_uint(f) - 1u);      // round toward zero
+    cells[i].x = (__float_as_uint(f) & ~kMarchCountMask) | (cells[i].x & kMarchCountMask);      // the low bits hold the cell's candidate count
+}
+hipError_t launch_march_clearance(const void* tris_f64, const void* nodes_f64, int n_nodes, const MarchGrid& G, uint2* cells,
+                                  double* coarse, hipStream_t s)
+{
+    const size_t n = (size_t)G.nx * G.ny * G.nz;
+    if (n == 0 || n_nodes <= 0) return hipSuccess;
+    const int kx = (G.nx + 7) / 8, ky = (G.ny + 7) / 8, kz = (G.nz + 7) / 8;
+    const size_t nc = (size_t)kx * ky * kz;
+    hipLaunchKernelGGL(k_march_coarse, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, s, reinterpret_cast<const TriD<double>*>(tris_f64),
+                       reinterpret_cast<const NodeD<double>*>(nodes_f64), n_nodes, G, kx, ky, kz, coarse);
+    hipLaunchKernelGGL(k_march_fine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const TriD<double>*>(tris_f64),
+                       reinterpret_cast<const NodeD<double>*>(nodes_f64), n_nodes, G, kx, ky, coarse, cells);
     return hipGetLastError();
 }
 
@@ -1221,13 +1606,15 @@ hipError_t launch_render_surface(const RenderParams& P, hipStream_t s)
 static inline unsigned nblk(size_t n, unsigned t) { return (unsigned)((n + t - 1) / t); }
 
 hipError_t launch_intersect_rays(const void* tris, const void* nodes, int n_tris, int n_nodes, const double* o,
-                                 const double* d, const double* tmax, size_t n, int use_bvh, int32_t* prim,
+                                 const double* d, const double* tmax, size_t n, int use_bvh, const MarchGrid* G, int32_t* prim,
                                  double* t, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
+    MarchGrid g;
+    if (G) g = *G; else { memset(&g, 0, sizeof g); if (use_bvh >= 2) use_bvh = 1; }
     hipLaunchKernelGGL(k_intersect_rays, dim3(nblk(n, 256)), dim3(256), 0, s,
                        reinterpret_cast<const TriD<double>*>(tris), reinterpret_cast<const NodeD<double>*>(nodes),
-                       n_tris, n_nodes, o, d, tmax, n, use_bvh, prim, t);
+                       n_tris, n_nodes, o, d, tmax, n, use_bvh, g, prim, t);
     return hipGetLastError();
 }
 hipError_t launch_triangle_intersect(const double* o, const double* d, const double* tris, size_t n, double* t,

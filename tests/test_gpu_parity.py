@@ -434,9 +434,21 @@ def test_large_mesh_in_global_memory(ctx):
     o = rs.uniform(-3.9, 3.9, size=(20000, 3))
     d = rs.normal(size=(20000, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
     tmax = np.where(rs.rand(20000) < 0.5, np.inf, rs.uniform(0.05, 4.0, size=20000))
+    # awkward rays for a grid march: axis-parallel directions (zero components), origins on cell walls / grid corners /
+    # outside the box (those take the BVH), hops far shorter than a cell
+    d[:300] = np.eye(3)[rs.randint(0, 3, 300)] * rs.choice([-1.0, 1.0], size=(300, 1))
+    d[300:600, 0] = 0.0; d[300:600] /= np.linalg.norm(d[300:600], axis=1, keepdims=True)
+    o[600:900] = np.round(o[600:900] * 8) / 8
+    o[900:1000] = rs.choice([-4.0, 4.0], size=(100, 3))
+    o[1000:1300] = rs.uniform(-6, 6, size=(300, 3))
+    tmax[1300:1600] = rs.uniform(1e-6, 1e-2, size=300)
     p1, t1 = B.intersect_bvh_batch(o, d, ordered, linear, tmax, True, ctx)
     p0, t0 = B.intersect_bvh_batch(o, d, ordered, linear, tmax, False, ctx)
     np.testing.assert_array_equal(p1, p0); np.testing.assert_array_equal(t1, t0)
+    # the grid march (what the walk uses for this mesh) answers every ray exactly as the brute-force scan does
+    for form in (2, 3):          # 2: the walk's wave-cooperative service, 3: the same march lane by lane
+        p2, t2 = B.intersect_bvh_batch(o, d, ordered, linear, tmax, form, ctx)
+        np.testing.assert_array_equal(p2, p0); np.testing.assert_array_equal(t2, t0)
     po, to = prob.oracle().intersect_rays(o, d, tmax, use_bvh=True)
     # index work is exact; a different triangle is only accepted as a tie: equal distance on two triangles that share
     # an edge (which of them claims a ray through the common edge is decided in the last bit, and the kernel fuses
@@ -456,6 +468,34 @@ def test_large_mesh_in_global_memory(ctx):
     check_counters(c, co, n)
     assert int((fx != fxo).sum()) == 0
     assert c["w_escaped_mesh"] > 0 and fx.sum() > 0
+
+
+def test_grid_march_equals_brute_force(ctx):
+    """The march grid on meshes of very different grain -- 30 wall-sized triangles (config 4's scene: every triangle spans
+    thousands of cells) and the 5140-triangle sphere -- at several resolutions: prim and t equal the brute-force scan's
+    bit for bit on 30000 rays (same tri_hit, same nearest / tie rule; only the set of triangles tested differs)."""
+    from light_transport_amd.src import bvh_new as B
+    rs = np.random.RandomState(21)
+    for (ordered, linear), half in ((S.cornell_scene(), 7.5), (S.sphere_in_box(3)[1:3], 4.0)):
+        n = 30000
+        o = rs.uniform(-half, half, size=(n, 3))
+        d = rs.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[:500] = np.eye(3)[rs.randint(0, 3, 500)] * rs.choice([-1.0, 1.0], size=(500, 1))
+        o[500:1500] = np.round(o[500:1500])                      # on cell walls of most resolutions
+        tmax = np.where(rs.rand(n) < 0.3, np.inf, rs.exponential(0.5, size=n))
+        p0, t0 = B.intersect_bvh_batch(o, d, ordered, linear, tmax, False, ctx)
+        for cells in ("16", "50", "128", ""):
+            if cells:
+                os.environ["LT_MARCH_CELLS"] = cells
+            else:
+                os.environ.pop("LT_MARCH_CELLS", None)
+            ctx.set_mesh(B.triangles_array(ordered), -np.ones(len(ordered), np.int32), -np.ones(len(ordered), np.int32),
+                         B.linear_bvh_arrays(linear))       # a fresh mesh: the grid is rebuilt at this resolution
+            ctx._mesh_key = None
+            for form in (2, 3):
+                p2, t2 = ctx.intersect_rays(o, d, tmax, form)
+                np.testing.assert_array_equal(p2, p0); np.testing.assert_array_equal(t2, t0)
+        assert (p0 >= 0).mean() > 0.3
 
 
 # ---------------------------------------------------------------- f3: meshes that came through the OBJ loader (G10)
@@ -483,7 +523,7 @@ def test_g10_obj_meshes_on_the_gpu(ctx, golden_dir, tmp_path, name):
     ordered, linear = B.build_linear_bvh(objects, 0)
     back = np.array([t.face_index for t in ordered])
     tri_xyz = v[f]
-    for use_bvh in (True, False):
+    for use_bvh in (True, False, 2):         # BVH, brute force, grid march
         prim, t = B.intersect_bvh_batch(g[name + "_origins"], g[name + "_dirs"], ordered, linear, None, use_bvh, ctx)
         got = np.where(prim >= 0, back[np.maximum(prim, 0)], -1)
         ties = S.check_hits_against_fixture(got, t, g[name + "_prim"], g[name + "_t"], g[name + "_second"], tri_xyz)
