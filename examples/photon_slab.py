@@ -30,6 +30,6 @@ print("%d photons, %d photon-steps: %.1f ms on the device = %.1f G photon-steps/
       % (n, c["steps"], tracer.kernel_ms(), c["steps"] / tracer.kernel_ms() / 1e6, dt))
 print("absorbed %.4f, diffuse reflectance %.4f, lost outside the grid %.2e (fractions of launched weight)"
       % (c["w_absorbed"] / n, c["w_escaped_top"] / n, c["w_lost_outside_grid"] / n))
-phi = fluence(absorbed, tissue.mu_a, grid.voxel_volume, n)
+phi = fluence(absorbed, slab, grid, n)      # (heterogeneous scenes: configure(..., quantity="fluence") and tracer.fluence())
 print("fluence on the beam axis at depth 0.05 / 1.05 / 5.05 mm: %.3f / %.3f / %.4f per mm^2"
       % (phi[0, 128, 128], phi[10, 128, 128], phi[50, 128, 128]))

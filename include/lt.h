@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 2
+#define LT_ABI_VERSION 3
 
 /* error codes */
 #define LT_OK 0
@@ -50,6 +50,13 @@ extern "C" {
                             0.0074 per photon: ~2e9 photons per grid);
                             read the grid out and zero it before that      */
 #define LT_FX_SCALE 1099511627776.0 /* 2^40 */
+
+/* what an interaction adds to its voxel (lt_set_tally_quantity) */
+#define LT_QUANTITY_ABSORBED 0 /* the absorbed weight dw = w mu_a / mu_t (default)           */
+#define LT_QUANTITY_FLUENCE 1  /* w / mu_t (= dw / mu_a, defined for mu_a = 0 too): the grid then holds
+                                  fluence x voxel volume x photons, correct in heterogeneous media -- no division
+                                  by a per-voxel mu_a afterwards.  Role of the normalised tally image / samples,
+                                  path_tracing_fix1.py:162-166.  Counters keep booking the absorbed weight.    */
 
 /* photon sources (lt_set_source) */
 #define LT_SRC_PENCIL 0      /* pos, dir                                   */
@@ -133,6 +140,8 @@ int lt_set_grid(lt_ctx* ctx, int nx, int ny, int nz, const double origin[3],
 int lt_set_source(lt_ctx* ctx, int type, const double pos[3], const double dir[3],
                   const double* extra, int start_medium);
 int lt_set_max_steps(lt_ctx* ctx, uint32_t max_steps);
+/* LT_QUANTITY_*; applies to subsequent launches (the grid is NOT rescaled: zero it when switching) */
+int lt_set_tally_quantity(lt_ctx* ctx, int quantity);
 /* launch geometry: resident workgroups per CU and threads per workgroup
  * (multiples of 64).  0 keeps the default. */
 int lt_set_launch_config(lt_ctx* ctx, int blocks_per_cu, int threads_per_block);

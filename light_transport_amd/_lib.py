@@ -29,7 +29,7 @@ SYMBOLS = [
     "lt_triangle_intersect", "lt_intersect_bounds", "lt_eval", "lt_rng_raw", "lt_device_info",
     "lt_set_surface_materials", "lt_set_lights", "lt_render_surface", "lt_set_vertex_capture", "lt_read_vertices",
     "lt_set_tally_mode", "lt_last_log_stages", "lt_reserve_log", "lt_render_surface_old", "lt_set_overlap", "lt_last_log_hot_tiles",
-    "lt_last_log_info",
+    "lt_last_log_info", "lt_set_tally_quantity",
 ]
 
 # lt_vertex as a NumPy record (112 bytes, same layout as the C struct)
@@ -218,6 +218,12 @@ class Context:
 
     def set_max_steps(self, n):
         self._ck(lib().lt_set_max_steps(self._h, C.c_uint32(int(n))), "lt_set_max_steps")
+
+    def set_tally_quantity(self, quantity):
+        """"absorbed" (default): an interaction adds the absorbed weight w mu_a / mu_t to its voxel; "fluence": it adds
+        w / mu_t, so that grid / (voxel volume x photons) IS the fluence, in heterogeneous media too (lt.h)."""
+        q = {"absorbed": 0, "fluence": 1}.get(quantity, quantity)
+        self._ck(lib().lt_set_tally_quantity(self._h, C.c_int(int(q))), "lt_set_tally_quantity")
 
     def set_launch_config(self, blocks_per_cu=0, threads_per_block=0):
         self._ck(lib().lt_set_launch_config(self._h, C.c_int(blocks_per_cu), C.c_int(threads_per_block)),

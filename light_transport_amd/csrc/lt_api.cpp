@@ -101,6 +101,7 @@ struct lt_ctx {
     int src_type = LT_SRC_PENCIL, start_medium = 0;
     double src_pos[3] = {0, 0, 0}, src_dir[3] = {0, 0, 1}, src_extra[6] = {0, 0, 0, 0, 0, 0};
     uint32_t max_steps = 1000000;
+    int quantity = LT_QUANTITY_ABSORBED;
     uint32_t max_vertices = 0, captured_max_vertices = 0;
     int tally_mode = 2;                 // 0: global atomics, 1: deposit log + partition + tile reduce, 2: auto (default)
     size_t log_budget = (size_t)16 << 30, default_log_budget = (size_t)16 << 30;   // bytes for the logs and their ping-pong copies
@@ -129,7 +130,7 @@ struct lt_ctx {
     DevBuf d_dmap, d_dmeta;
     bool dmap_valid = false, tile_cnt_ready = false, last_hot = false;
     uint32_t dmap_tiles = 0, dmap_bits2 = 0;      // the partition geometry the map was made for
-    bool tables_dirty = true;
+    bool tables_dirty = true, media_dirty = false;
     bool timed = false;
 
     int fail(int code, const char* fmt, ...)
@@ -159,7 +160,7 @@ struct lt_ctx {
 namespace {
 
 template <typename R>
-void fill_media(const std::vector<lt_medium>& in, std::vector<MedD<R>>& out)
+void fill_media(const std::vector<lt_medium>& in, int quantity, std::vector<MedD<R>>& out)
 {
     out.resize(in.size());
     for (size_t i = 0; i < in.size(); i++) {
@@ -174,6 +175,8 @@ void fill_media(const std::vector<lt_medium>& in, std::vector<MedD<R>>& out)
         m.one_m_g2 = (R)1 - g * g;
         m.one_p_g2 = (R)1 + g * g;
         m.inv_2g = g != 0 ? (R)1 / ((R)2 * g) : (R)0;
+        m.dep = quantity == LT_QUANTITY_FLUENCE ? m.inv_mu_t : m.absorb;
+        m.pad_ = 0;
     }
 }
 
@@ -357,16 +360,21 @@ int build_march_grid(lt_ctx* c)
 
 int upload_tables(lt_ctx* c)
 {
-    if (!c->tables_dirty) return LT_OK;
+    if (!c->tables_dirty && !c->media_dirty) return LT_OK;
     int rc;
     // staging vectors live until the stream has drained (pageable H2D copies)
     std::vector<MedD<double>> m64; std::vector<MedD<float>> m32;
     std::vector<double> z64; std::vector<float> z32;
     std::vector<TriD<double>> t64; std::vector<TriD<float>> t32;
     std::vector<NodeD<double>> n64; std::vector<NodeD<float>> n32;
-    fill_media(c->media, m64); fill_media(c->media, m32);
+    fill_media(c->media, c->quantity, m64); fill_media(c->media, c->quantity, m32);
     if ((rc = upload(c, c->d_media[0], m64))) return rc;
     if ((rc = upload(c, c->d_media[1], m32))) return rc;
+    if (!c->tables_dirty) {      // only the media table changed (lt_set_tally_quantity): the geometry tables stay
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->media_dirty = false;
+        return LT_OK;
+    }
     if (c->have_layers) {
         z64 = c->z_bounds;
         z32.assign(z64.begin(), z64.end());
@@ -420,7 +428,7 @@ int upload_tables(lt_ctx* c)
         }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->tables_dirty = false;
+    c->tables_dirty = false; c->media_dirty = false;
     return LT_OK;
 }
 
@@ -924,6 +932,15 @@ int lt_set_max_steps(lt_ctx* c, uint32_t max_steps)
     CHECK_CTX(c);
     if (max_steps == 0) return c->fail(LT_E_INVALID, "lt_set_max_steps: must be > 0");
     c->max_steps = max_steps;
+    return LT_OK;
+}
+
+int lt_set_tally_quantity(lt_ctx* c, int quantity)
+{
+    CHECK_CTX(c);
+    if (quantity != LT_QUANTITY_ABSORBED && quantity != LT_QUANTITY_FLUENCE)
+        return c->fail(LT_E_INVALID, "lt_set_tally_quantity: LT_QUANTITY_ABSORBED or LT_QUANTITY_FLUENCE");
+    if (quantity != c->quantity) { c->quantity = quantity; c->media_dirty = true; }     // the media table carries the factor
     return LT_OK;
 }
 

@@ -14,6 +14,8 @@ template <typename R>
 struct MedD {
     R mu_t, inv_mu_t, absorb, g;
     R n, one_m_g2, one_p_g2, inv_2g;
+    R dep;   // what a voxel receives per unit of photon weight at an interaction: absorb, or inv_mu_t (LT_QUANTITY_FLUENCE)
+    R pad_;
 };
 
 // Triangle record: role of PreComputedTriangle (primitives.py:99-112).

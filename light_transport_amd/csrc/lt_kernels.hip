@@ -443,6 +443,7 @@ template <typename R> struct MarchWave {        // per wave, in LDS
     typename MarchBits<R>::type slot_t[64];     // best t per ray (bits), starts at the ray's tmax
     unsigned slot_i[64];                        // triangle of that t (lowest id on ties)
     R ray[9][64];                               // origin, direction, 1 / direction (inf for an axis the ray does not move along)
+    R held[4][64];                              // walk_kernel_m: the prepared step of a lane in a query (free path, three decision uniforms)
     unsigned q_item[kMarchQ];                   // lane << 26 | position in MarchGrid::list
     typename MarchBits<R>::type q_t[kMarchQ];   // t of the item's test (all ones: no hit)
 };
@@ -514,13 +515,19 @@ LT_DEV bool march_round(const MarchGrid& G, MarchWave<R>* W, bool& marching, boo
         }
     }
     if (!m) marching = false;
-    unsigned incl = n;                    // inclusive prefix sum of n over the lanes
+    // exclusive prefix sum of n (< 64) over the lanes, bit by bit with ballots: scalar / VALU work only.  (Six __shfl_up
+    // steps -- ds_bpermute round trips -- cost the walk 3.5-4 %: teapot 18.6 -> 19.3-19.4e9 steps/s, profiles/r03a_*.log)
+    unsigned excl = 0, total_ = 0;
 #pragma unroll
-    for (unsigned off = 1; off < 64; off <<= 1) { const unsigned v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
-    const unsigned excl = incl - n, cap = kMarchQ - qn;
+    for (unsigned b = 0; b < 6; b++) {
+        const unsigned long long mb = __ballot((n >> b) & 1u);
+        excl += __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u)) << b;
+        total_ += (unsigned)__popcll(mb) << b;
+    }
+    const unsigned incl = excl + n, cap = kMarchQ - qn;
     const bool blocked = incl > cap;                            // does not fit: the lane stays on this cell until the queue has drained
     const unsigned long long bm = __ballot(blocked);            // (the blocked lanes are a suffix: the prefix sums ascend)
-    const unsigned pushed = bm ? (unsigned)__shfl(excl, __ffsll((long long)bm) - 1, 64) : (unsigned)__shfl(incl, 63, 64);
+    const unsigned pushed = bm ? (unsigned)__builtin_amdgcn_readlane((int)excl, __ffsll((long long)bm) - 1) : total_;
     if (!blocked) for (unsigned k = 0; k < n; k++) W->q_item[qn + excl + k] = (lane << 26) | (lst + k);
     qn += pushed;
     if (m && !blocked) {

@@ -104,9 +104,10 @@ class PhotonTracer:
     def __init__(self, device_id=0, ctx=None):
         self.ctx = ctx or _lib.Context(device_id)
         self.grid = None
-        self._mu_a_of_voxel = None
+        self.quantity = "absorbed"
+        self.photons = 0          # traced since the last reset (the fluence normalisation)
 
-    def configure(self, geometry, grid, source, primitives=None, linear_bvh=None, max_steps=None):
+    def configure(self, geometry, grid, source, primitives=None, linear_bvh=None, max_steps=None, quantity="absorbed"):
         ctx = self.ctx
         ctx.set_media([m.as_tuple() for m in geometry.media])
         start_medium = 0
@@ -137,21 +138,37 @@ class PhotonTracer:
         ctx.set_overlap(0)
         ctx.set_launch_config(0, 0)
         ctx.set_vertex_capture(0)
-        self.grid = grid
+        ctx.set_tally_quantity(quantity)     # "absorbed": weight absorbed per voxel; "fluence": w / mu_t per interaction
+        self.grid, self.quantity, self.photons = grid, quantity, 0
         return self
 
     def run(self, n_photons, seed=0, photon_offset=0, rng_table=None, f32_walk=False, wait=True):
         self.ctx.launch(n_photons, seed=seed, photon_offset=photon_offset, rng_table=rng_table, f32_walk=f32_walk)
+        self.photons += int(n_photons)
         if wait:
             self.ctx.sync()
         return self
 
     def reset(self):
         self.ctx.zero_tally()
+        self.photons = 0
 
     def absorbed(self):
-        """float64 [nz, ny, nx]: absorbed photon weight per voxel."""
+        """float64 [nz, ny, nx]: absorbed photon weight per voxel (configure(..., quantity="absorbed"))."""
+        if self.quantity != "absorbed":
+            raise ValueError("this tracer tallies %r: absorbed() needs configure(..., quantity='absorbed')" % self.quantity)
         return self.ctx.read_grid()
+
+    def fluence(self):
+        """float64 [nz, ny, nx]: fluence per launched photon (1 / area) -- the grid of a tracer configured with
+        quantity="fluence", where every interaction adds w / mu_t to its voxel, divided by voxel volume x photons.
+        Correct in heterogeneous media (two layers, a mesh of another medium) and in media that do not absorb
+        (mu_a = 0), where absorbed / mu_a has no meaning.  Normalised tally, role of path_tracing_fix1.py:162-166."""
+        if self.quantity != "fluence":
+            raise ValueError("this tracer tallies %r: fluence() needs configure(..., quantity='fluence')" % self.quantity)
+        if self.photons <= 0:
+            raise ValueError("fluence(): nothing traced since the last reset")
+        return self.ctx.read_grid() / (self.grid.voxel_volume * float(self.photons))
 
     def absorbed_raw(self):
         return self.ctx.read_grid_raw()
@@ -184,18 +201,38 @@ def generate_light_subpaths(tracer, n_photons, max_depth, seed=0, photon_offset=
     return out
 
 
-def fluence(absorbed, mu_a, voxel_volume, n_photons):
-    """Host post-step (Appendix C.4): fluence = absorbed / (mu_a * dV * N)."""
-    return np.asarray(absorbed, dtype=np.float64) / (float(mu_a) * float(voxel_volume) * float(n_photons))
+def fluence(absorbed, geometry, grid, n_photons):
+    """Host post-step for an ABSORBED-weight grid of a LayeredSlab whose layer planes lie on voxel boundaries (Appendix
+    C.4): fluence = absorbed / (mu_a(layer of the voxel) * dV * N), NaN where mu_a = 0.  Anything else -- a mesh, a plane
+    inside a voxel, a medium that does not absorb -- has no per-voxel mu_a: trace with quantity="fluence" instead, where
+    the device tallies w / mu_t directly (PhotonTracer.fluence / trace_photons(..., quantity="fluence"))."""
+    if not isinstance(geometry, LayeredSlab):
+        raise TypeError("fluence(): a per-voxel mu_a exists for a LayeredSlab only; use quantity='fluence' for meshes")
+    a = np.asarray(absorbed, dtype=np.float64)
+    nz = a.shape[0]
+    z_lo = grid.origin[2] + grid.voxel[2] * np.arange(nz)
+    z_hi = z_lo + grid.voxel[2]
+    mu_a = np.full(nz, np.nan)
+    tol = 1e-9 * grid.voxel[2]
+    for k, m in enumerate(geometry.media):
+        inside = (z_lo >= geometry.z_bounds[k] - tol) & (z_hi <= geometry.z_bounds[k + 1] + tol)
+        mu_a[inside] = m.mu_a
+    straddle = ~np.isfinite(mu_a) & (z_hi > geometry.z_bounds[0] + tol) & (z_lo < geometry.z_bounds[-1] - tol)
+    if straddle.any():
+        raise ValueError("fluence(): a layer plane cuts through voxel row(s) %s; use quantity='fluence'" % np.flatnonzero(straddle)[:4])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out = a / (np.where(mu_a > 0, mu_a, np.nan)[:, None, None] * grid.voxel_volume * float(n_photons))
+    return out
 
 
 def trace_photons(geometry, primitives, linear_bvh, n_photons, seed=0, grid=None, source=None, rng_table=None,
-                  f32_walk=False, max_steps=None, device_id=0, return_counters=False):
-    """One call, one array back: absorbed weight per voxel, float64 [nz, ny, nx]."""
+                  f32_walk=False, max_steps=None, device_id=0, return_counters=False, quantity="absorbed"):
+    """One call, one array back, float64 [nz, ny, nx]: absorbed weight per voxel, or -- quantity="fluence" -- the
+    fluence per launched photon (every interaction adds w / mu_t on the device; correct in heterogeneous media)."""
     if grid is None or source is None:
         raise ValueError("trace_photons needs grid= and source=")
     tr = PhotonTracer(ctx=_lib.default_context(device_id))
-    tr.configure(geometry, grid, source, primitives, linear_bvh, max_steps)
+    tr.configure(geometry, grid, source, primitives, linear_bvh, max_steps, quantity)
     tr.run(n_photons, seed=seed, rng_table=rng_table, f32_walk=f32_walk)
-    out = tr.absorbed()
+    out = tr.fluence() if quantity == "fluence" else tr.absorbed()
     return (out, tr.counters()) if return_counters else out

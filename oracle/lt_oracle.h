@@ -51,6 +51,7 @@ typedef struct lto_scene {
     double src_pos[3], src_dir[3], src_extra[6];
     int start_medium;
     uint32_t max_steps;
+    int quantity;                 /* LT_QUANTITY_ABSORBED / LT_QUANTITY_FLUENCE (lt_set_tally_quantity) */
 } lto_scene;
 
 /* Walk photons [photon_offset, photon_offset+n).  grid_f64 (nullable) and

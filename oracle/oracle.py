@@ -49,7 +49,7 @@ class _Scene(C.Structure):
         ("med_back", C.POINTER(C.c_int32)), ("n_nodes", C.c_int), ("nodes", C.POINTER(BvhNode)),
         ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("origin", C.c_double * 3), ("voxel", C.c_double * 3),
         ("src_type", C.c_int), ("src_pos", C.c_double * 3), ("src_dir", C.c_double * 3),
-        ("src_extra", C.c_double * 6), ("start_medium", C.c_int), ("max_steps", C.c_uint32),
+        ("src_extra", C.c_double * 6), ("start_medium", C.c_int), ("max_steps", C.c_uint32), ("quantity", C.c_int),
     ]
 
 
@@ -94,7 +94,7 @@ def nodes_to_struct(nodes):
 class OracleScene:
     """Plain description of one transport problem; mirrors the lt_set_* calls."""
 
-    def __init__(self, media, grid_shape, origin, voxel, layers=None, mesh=None, source=None, max_steps=1000000):
+    def __init__(self, media, grid_shape, origin, voxel, layers=None, mesh=None, source=None, max_steps=1000000, quantity=0):
         self.media = [tuple(map(float, m)) for m in media]  # (mu_a, mu_s, g, n)
         self.nx, self.ny, self.nz = (int(v) for v in grid_shape)  # (nx, ny, nz)
         self.origin = tuple(map(float, origin))
@@ -103,6 +103,7 @@ class OracleScene:
         self.mesh = mesh      # dict(verts[T,3,3], med_front, med_back, nodes)
         self.source = source or dict(type=0, pos=(0, 0, 0), dir=(0, 0, 1), extra=(0,) * 6, start_medium=0)
         self.max_steps = int(max_steps)
+        self.quantity = {"absorbed": 0, "fluence": 1}.get(quantity, quantity)     # lt_set_tally_quantity
         self._keep = []
 
     def _c(self):
@@ -138,6 +139,7 @@ class OracleScene:
         s.src_extra[:] = [float(x) for x in ex[:6]]
         s.start_medium = int(src.get("start_medium", 0))
         s.max_steps = self.max_steps
+        s.quantity = int(self.quantity)
         return s
 
     def run(self, n_photons, seed=0, photon_offset=0, rng_table=None, walk_f32=False, threads=1,

@@ -30,6 +30,7 @@ class Problem:
         s = self.source
         ctx.set_source(s.get("type", 0), s["pos"], s["dir"], s.get("extra"), s.get("start_medium", 0))
         ctx.set_max_steps(self.max_steps)
+        ctx.set_tally_quantity("absorbed")
         return ctx
 
 

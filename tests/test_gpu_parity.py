@@ -423,6 +423,48 @@ def test_trace_photons_one_call_api(ctx):
     S.assert_grid_close(dose, go)
 
 
+# ---------------------------------------------------------------- tally quantity: fluence in heterogeneous media
+def test_fluence_quantity(ctx):
+    """lt_set_tally_quantity(LT_QUANTITY_FLUENCE): an interaction adds w / mu_t (= dw / mu_a) to its voxel, so the grid is
+    fluence x dV x N without a per-voxel mu_a.  GPU == oracle bit for bit (u64 fixed point) on the two-layer slab and on the
+    Cornell cavity + cone (two media, mesh); the counters keep booking absorbed weight (identical to an absorbed-weight run);
+    on a slab whose layer plane lies on a voxel boundary  sum_v grid[v] mu_a(layer of v) == w_absorbed;  a layer that does
+    not absorb (mu_a = 0) has fluence although it has no absorbed weight."""
+    n = 20000
+    for prob in (S.two_layer(n=64, voxel=0.05), S.cornell(32)):
+        prob.apply(ctx, "u64fx"); ctx.set_tally_quantity("fluence")
+        ctx.launch(n, seed=9); ctx.sync()
+        fx, c = ctx.read_grid_raw(), ctx.read_counters()
+        o = prob.oracle(); o.quantity = 1
+        _, fxo, co = o.run(n, seed=9, threads=8, want_fx=True, want_f64=False)
+        check_counters(c, co, n)
+        assert np.array_equal(fx, fxo)
+        ctx.set_tally_quantity("absorbed"); ctx.zero_tally()
+        ctx.launch(n, seed=9); ctx.sync()
+        ca, fa = ctx.read_counters(), ctx.read_grid_raw()
+        # the walk itself is unchanged: identical step count; w_absorbed is a float sum over lanes / waves whose order
+        # depends on which lane traced which photon, so two runs agree to rounding (1 ulp seen), not bitwise
+        assert ca["steps"] == c["steps"], (ca["steps"], c["steps"])
+        assert abs(ca["w_absorbed"] - c["w_absorbed"]) <= 1e-12 * c["w_absorbed"], (ca["w_absorbed"], c["w_absorbed"])
+        assert not np.array_equal(fa, fx)
+    # conservation through the fluence grid: layer plane z = 0.1 on the boundary of voxel rows 1 | 2 (voxel 0.05)
+    prob = S.two_layer(n=64, voxel=0.05)
+    prob.apply(ctx, "f64"); ctx.set_tally_quantity("fluence")
+    ctx.launch(200000, seed=3); ctx.sync()
+    g, c = ctx.read_grid(), ctx.read_counters()
+    mu_a = np.where(np.arange(64) < 2, 0.43, 0.27)
+    assert abs((g * mu_a[:, None, None]).sum() - c["w_absorbed"]) < 1e-9 * 200000
+    # a medium that does not absorb: fluence, but no absorbed weight, in its rows
+    prob.media = [(0.0, 10.7, 0.79, 1.5), (0.27, 18.7, 0.82, 1.4)]
+    prob.apply(ctx, "f64"); ctx.set_tally_quantity("fluence")
+    ctx.launch(50000, seed=4); ctx.sync()
+    gf = ctx.read_grid()
+    ctx.set_tally_quantity("absorbed"); ctx.zero_tally(); ctx.launch(50000, seed=4); ctx.sync()
+    ga = ctx.read_grid()
+    assert gf[:2].sum() > 100.0 and ga[:2].sum() == 0.0 and ga[2:].sum() > 0.0
+    ctx.set_tally_quantity("absorbed")
+
+
 # ---------------------------------------------------------------- f1: meshes beyond the LDS budget, SAH builder
 def test_large_mesh_in_global_memory(ctx):
     """5140 triangles / ~10^4 nodes (~1.2 MB of tables): traversed in place in global memory (GEOM 2),

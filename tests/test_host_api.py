@@ -35,7 +35,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(L, n), "missing export " + n
     assert sorted(_lib.SYMBOLS) == names
-    assert L.lt_abi_version() == 2
+    assert L.lt_abi_version() == 3
 
 
 def test_no_cpu_fallback_create_fails_loudly():
@@ -154,8 +154,14 @@ def test_photon_tracing_objects():
     np.testing.assert_array_equal(slab.z_bounds, [0.0, 0.1, np.inf])
     g = PT.VoxelGrid((8, 9, 10), (0, 0, 0), 0.5)
     assert g.voxel == (0.5, 0.5, 0.5) and abs(g.voxel_volume - 0.125) < 1e-15
-    f = PT.fluence(np.ones((2, 2, 2)), 0.1, 0.125, 100)
-    np.testing.assert_allclose(f, 1.0 / (0.1 * 0.125 * 100))
+    # host post-step for an absorbed-weight grid: per-row mu_a of a layered slab whose planes lie on voxel boundaries
+    g2 = PT.VoxelGrid((2, 2, 4), (0, 0, 0), (0.5, 0.5, 0.05))
+    f = PT.fluence(np.ones((4, 2, 2)), slab, g2, 100)
+    np.testing.assert_allclose(f[:2], 1.0 / (0.43 * g2.voxel_volume * 100)); np.testing.assert_allclose(f[2:], 1.0 / (0.27 * g2.voxel_volume * 100))
+    with pytest.raises(ValueError):          # a plane inside a voxel row: no per-voxel mu_a -> trace with quantity="fluence"
+        PT.fluence(np.ones((4, 2, 2)), slab, PT.VoxelGrid((2, 2, 4), (0, 0, 0), (0.5, 0.5, 0.04)), 100)
+    with pytest.raises(TypeError):
+        PT.fluence(np.ones((4, 2, 2)), PT.MeshVolume([PT.OpticalMedium(0.1, 1.0, 0.0)]), g2, 100)
     with pytest.raises(ValueError):
         PT.LayeredSlab([], [])
     prob = S.cornell(16)

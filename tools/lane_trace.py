@@ -9,9 +9,14 @@ if sys.argv[1] == "run":
     from tests import scenes as S
     lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     case = sys.argv[3] if len(sys.argv) > 3 else "c2"
-    prob, n, mode = {"c2": (S.slab(n=256, voxel=0.1), 10 ** 7, "log"), "c3": (S.two_layer(n=256, voxel=0.05), 10 ** 7, "log"),
-                     "c4": (S.cornell(256), 10 ** 7, "auto"), "c5": (S.two_layer(n=512, voxel=0.025), 12500000, "log"),
-                     "sphere": (S.sphere_in_box(4, split_method=0)[0], 10 ** 7, "log")}[case]
+    if case in ("teapot", "cow", "pumpkin"):      # the reference's OBJ assets (fixture G10) in a closed box
+        import numpy as np
+        g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g10_obj_meshes.npz"))
+        prob, n, mode = S.obj_in_box(g[case + "_verts"], g[case + "_faces"])[0], 10 ** 7, "log"
+    else:
+        prob, n, mode = {"c2": lambda: (S.slab(n=256, voxel=0.1), 10 ** 7, "log"), "c3": lambda: (S.two_layer(n=256, voxel=0.05), 10 ** 7, "log"),
+                         "c4": lambda: (S.cornell(256), 10 ** 7, "auto"), "c5": lambda: (S.two_layer(n=512, voxel=0.025), 12500000, "log"),
+                         "sphere": lambda: (S.sphere_in_box(4, split_method=0)[0], 10 ** 7, "log")}[case]()
     ctx = lt.Context(0)
     prob.apply(ctx, "f64"); ctx.set_tally_mode(mode); ctx.set_overlap(lanes)
     for r in range(3):
