@@ -100,6 +100,9 @@ def main():
     if sys.argv[1:] == ["g9"]:          # only one fixture; the others are unchanged by it
         g9_render_old(R)
         return
+    if sys.argv[1:] == ["g10b"]:
+        g10b_obj_meshes_more(R)
+        return
     if sys.argv[1:] == ["g10"]:
         g10_obj_meshes(R)
         return
@@ -220,6 +223,7 @@ def main():
     g8_render(R)
     g9_render_old(R)
     g10_obj_meshes(R)
+    g10b_obj_meshes_more(R)
     print("golden vectors written to", OUT)
 
 
@@ -287,6 +291,52 @@ def g10_obj_meshes(R):
         out[name + "_second"] = np.concatenate([r[2] for r in res])
         print(name, len(v), "vertices", len(f), "triangles", int((out[name + "_prim"] >= 0).sum()), "of", nr, "rays hit", flush=True)
     np.savez_compressed(os.path.join(OUT, "g10_obj_meshes.npz"), **out)
+
+
+def g10b_obj_meshes_more(R):
+    """G10b: the REST of the reference's OBJ assets -- examples/obj/{wine-glass,glass,diamond,square}.obj (wine-glass: 12 673
+    quad faces `f a//n b//n c//n d//n`, the largest asset; glass: plain quads; diamond: 9 triangles; square: one quad) --
+    exactly as g10_obj_meshes does it (own minimal reader, fan triangulation, the reference's PreComputedTriangle and
+    triangle_intersect, brute force over every triangle), written to a file of its own with its own random stream so that
+    g10_obj_meshes.npz stays byte for byte what it was."""
+    import multiprocessing as mp
+    obj_dir = os.path.join(REF, "LightTransportSimulator", "light_transport", "examples", "obj")
+    mat = R["material"].Material(R["material"].Color(np.zeros(3), np.ones(3), np.ones(3)), 1.0, 0.1, 1.5)
+    PCT = R["primitives"].PreComputedTriangle
+    tri_fn, eps = R["intersects"].triangle_intersect, R["constants"].EPSILON
+    out = {}
+    rs = np.random.RandomState(1011)
+    for name, nr in (("wine-glass", 600), ("glass", 600), ("diamond", 400), ("square", 200)):
+        key = name.replace("-", "_")
+        verts, faces = [], []
+        for line in open(os.path.join(obj_dir, name + ".obj"), errors="replace"):
+            p = line.split()
+            if not p:
+                continue
+            if p[0] == "v":
+                verts.append([float(x) for x in p[1:4]])
+            elif p[0] == "f":
+                idx = [int(tok.split("/")[0]) for tok in p[1:]]
+                idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                faces += [[idx[0], idx[k], idx[k + 1]] for k in range(1, len(idx) - 1)]
+        v, f = np.array(verts, dtype=np.float64), np.array(faces, dtype=np.int32)
+        nz = np.array([np.dot(n, n) > 0 for n in np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])])
+        f = f[nz]
+        ref_tris = [PCT(h4(v[a], 1), h4(v[b], 1), h4(v[c], 1), mat) for a, b, c in f]
+        lo, hi = v.min(axis=0), v.max(axis=0)
+        ext = np.maximum(hi - lo, 1e-3 * float((hi - lo).max()))      # (square.obj is flat: give the ray cloud some depth)
+        org = lo - 0.3 * ext + rs.rand(nr, 3) * 1.6 * ext
+        tgt = lo + rs.rand(nr, 3) * (hi - lo)
+        dirs = tgt - org; dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        chunks = np.array_split(np.arange(nr), 16)
+        with mp.get_context("fork").Pool(8) as pool:
+            res = pool.map(_g10_chunk, [(tri_fn, eps, ref_tris, org[c], dirs[c]) for c in chunks])
+        out[key + "_verts"] = v; out[key + "_faces"] = f
+        out[key + "_origins"] = org; out[key + "_dirs"] = dirs
+        out[key + "_prim"] = np.concatenate([r[0] for r in res]); out[key + "_t"] = np.concatenate([r[1] for r in res])
+        out[key + "_second"] = np.concatenate([r[2] for r in res])
+        print(name, len(v), "vertices", len(f), "triangles", int((out[key + "_prim"] >= 0).sum()), "of", nr, "rays hit", flush=True)
+    np.savez_compressed(os.path.join(OUT, "g10b_obj_meshes_more.npz"), **out)
 
 
 def g8_render(R):

@@ -281,11 +281,23 @@ def test_f32_oracle_tracks_f64_statistically():
 
 
 # ---------------------------------------------------------------- G10: the reference's OBJ assets (f3)
-@pytest.mark.parametrize("name", ["teapot", "cow", "pumpkin"])
+G10B = [("wine-glass", "wine_glass"), ("glass", "glass"), ("diamond", "diamond"), ("square", "square")]
+
+
+def _g10_file(golden_dir, name):
+    """(fixture, key prefix): teapot / cow / pumpkin live in g10_obj_meshes.npz, the rest of the reference's assets in
+    g10b_obj_meshes_more.npz (same generator, tests/golden/make_golden.py)."""
+    more = dict(G10B)
+    if name in more:
+        return np.load(os.path.join(golden_dir, "g10b_obj_meshes_more.npz")), more[name]
+    return np.load(os.path.join(golden_dir, "g10_obj_meshes.npz")), name
+
+
+@pytest.mark.parametrize("name", ["teapot", "cow", "pumpkin", "wine-glass", "glass", "diamond", "square"])
 def test_g10_oracle_nearest_hit_on_obj_meshes(golden_dir, name):
     """Oracle traversal (SAH BVH over loader-built PreComputedTriangles, and brute force) against the reference's
-    triangle_intersect run over every triangle of the reference's own meshes."""
-    g = np.load(os.path.join(golden_dir, "g10_obj_meshes.npz"))
+    triangle_intersect run over every triangle of the reference's own meshes -- ALL of examples/obj/*.obj."""
+    g, name = _g10_file(golden_dir, name)
     from light_transport_amd.src.io import triangles_from_mesh
     from light_transport_amd.src import bvh_new as B, constants as K
     v, f = g[name + "_verts"], g[name + "_faces"]
@@ -305,12 +317,13 @@ def test_g10_oracle_nearest_hit_on_obj_meshes(golden_dir, name):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference assets only exist in the build container")
-@pytest.mark.parametrize("name", ["teapot", "cow", "pumpkin"])
+@pytest.mark.parametrize("name", ["teapot", "cow", "pumpkin", "wine-glass", "glass", "diamond", "square"])
 def test_g10_loader_reads_the_reference_assets(golden_dir, name):
-    """src/io.read_obj on the reference's files == the fixture's independently parsed vertices and faces."""
-    g = np.load(os.path.join(golden_dir, "g10_obj_meshes.npz"))
-    from light_transport_amd.src.io import read_obj, load_obj
+    """src/io.read_obj on the reference's files == the fixture's independently parsed vertices and faces (face forms seen:
+    `f a b c`, `f a b c d`, `f a//n b//n c//n [d//n]`, runs of blanks)."""
     path = "/root/reference/LightTransportSimulator/light_transport/examples/obj/%s.obj" % name
+    g, name = _g10_file(golden_dir, name)
+    from light_transport_amd.src.io import read_obj, load_obj
     v, f = read_obj(path)
     assert np.array_equal(v, g[name + "_verts"])
     nz = np.einsum("ij,ij->i", *(2 * [np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])])) > 0
