@@ -131,6 +131,14 @@ int lt_set_layers(lt_ctx* ctx, const double* z_bounds, const int32_t* medium_idx
 int lt_set_mesh(lt_ctx* ctx, const double* verts, const int32_t* med_front,
                 const int32_t* med_back, int n_tris, const lt_bvh_node* nodes,
                 int n_nodes);
+/* Host BVH build + flatten in one call -- role of build_bvh + flatten_bvh (bvh_new.py:148-300) over BoundedBox-es of the
+ * triangles (bvh_new.py:11-15), with the reference's defects B1 (second_child_offset) and B2 (partition on a copy) fixed.
+ * Pure host code: no ctx, no device.  verts [n_tris][3][3]; split_method 1 = midpoint (the reference's hard-wired choice,
+ * :149), 0 = binned surface-area heuristic (its dormant branch, :198-258).  order_out [n_tris]: ordered_prims[i] is input
+ * triangle order_out[i]; nodes_out [max_nodes >= 2 n_tris - 1], pre-order, as lt_set_mesh takes them.  The tree equals
+ * the Python mirror's (light_transport_amd/src/bvh_new.py build_bvh / flatten_bvh) node for node. */
+int lt_build_bvh(const double* verts, int n_tris, int split_method, int32_t* order_out, lt_bvh_node* nodes_out,
+                 int max_nodes, int* n_nodes_out);
 /* voxel grid (tally) -- role of Scene.image (scene.py:66).  C-order
  * [nz][ny][nx]; allocates and zeroes the device grid and the counters. */
 int lt_set_grid(lt_ctx* ctx, int nx, int ny, int nz, const double origin[3],
@@ -140,6 +148,21 @@ int lt_set_grid(lt_ctx* ctx, int nx, int ny, int nz, const double origin[3],
 int lt_set_source(lt_ctx* ctx, int type, const double pos[3], const double dir[3],
                   const double* extra, int start_medium);
 int lt_set_max_steps(lt_ctx* ctx, uint32_t max_steps);
+/* Experiment knobs -- tuning constants and diagnostic switches that tests and measurement tools vary; results do not
+ * depend on any of them (the tests hold that down bit for bit).  value < 0 restores the built-in default.  Each knob is
+ * seeded ONCE, in lt_create, from the environment variable LT_<KEY IN CAPITALS>; the library reads the environment
+ * nowhere else.  Keys:
+ *   query_min          meshes in LDS: lanes a wave gathers before it serves their surface queries; meshes beyond LDS:
+ *                      answered-but-untested queries that trigger a drain of the candidate queue            (1..64)
+ *   log_bits2, log_hot two-pass partition: width of the second digit; cap on the number of hot tiles (0: plain two-pass)
+ *   overlap_walk_bpc   workgroups per CU of a walk that shares the device with another lane's reduction     (1..8)
+ *   diag_no_tally      time the walk without deposition;   log_timing  print per-stage device times of every launch
+ *   -- taking effect when the mesh tables are next built (lt_set_mesh + launch / query):
+ *   march_cells, march_scale_milli   march grid: cells along the longest axis / cell size in 1/1000 of the default
+ *   clearance_cells    clearance grid of meshes in LDS: cells along the longest axis
+ *   no_march, no_clearance, no_near_lists   switch the shortcut off (every query then takes the slower exact path)
+ *   march_info         print the march grid's dimensions when it is built */
+int lt_set_tuning(lt_ctx* ctx, const char* key, int64_t value);
 /* LT_QUANTITY_*; applies to subsequent launches (the grid is NOT rescaled: zero it when switching) */
 int lt_set_tally_quantity(lt_ctx* ctx, int quantity);
 /* launch geometry: resident workgroups per CU and threads per workgroup
@@ -208,7 +231,7 @@ int lt_last_log_info(lt_ctx* ctx, uint64_t* records, uint64_t* overflow_records,
  * the scene is known (the pilot batch), the tiles that hold most records ("hot") leave the first pass in their final
  * form and only the rest goes through the second.  Reports, for the last log-mode lt_launch (blocking): how many tiles
  * were hot (0: plain two-pass or one-pass form) and the record count of the pilot histogram that made a tile hot.
- * LT_LOG_HOT=<n> in the environment caps the number of hot tiles (0 switches the form off). */
+ * lt_set_tuning("log_hot", n) caps the number of hot tiles (0 switches the form off). */
 int lt_last_log_hot_tiles(lt_ctx* ctx, uint32_t* hot_tiles, uint32_t* threshold);
 
 /* ---- readback ---------------------------------------------------------- */
@@ -349,6 +372,12 @@ int lt_set_vertex_capture(lt_ctx* ctx, uint32_t max_vertices_per_photon);
 /* vertices [n_photons][max_vertices_per_photon] and counts [n_photons] of the
  * LAST lt_launch (photon index = id - photon_offset); blocking D2H. */
 int lt_read_vertices(lt_ctx* ctx, lt_vertex* vertices_out, uint32_t* counts_out, uint64_t n_photons);
+
+/* What accelerates surface queries on the current mesh (built at the first launch / query after lt_set_mesh; this call
+ * builds it if need be).  kind: 0 none (BVH only), 1 clearance grid with near-triangle lists (meshes whose tables fit
+ * LDS), 2 march grid (meshes beyond LDS), 3 both (the f32 tables fit LDS, the f64 ones do not).  march_dims /
+ * clearance_dims: cells along x, y, z (zeros if absent); march_entries: (cell, triangle) pairs in the candidate lists. */
+int lt_mesh_accel_info(lt_ctx* ctx, int* kind, int march_dims[3], uint64_t* march_entries, int clearance_dims[3]);
 
 /* device description for bench reports */
 int lt_device_info(lt_ctx* ctx, char* name, size_t name_len, int* n_cus,

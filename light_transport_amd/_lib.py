@@ -29,7 +29,7 @@ SYMBOLS = [
     "lt_triangle_intersect", "lt_intersect_bounds", "lt_eval", "lt_rng_raw", "lt_device_info",
     "lt_set_surface_materials", "lt_set_lights", "lt_render_surface", "lt_set_vertex_capture", "lt_read_vertices",
     "lt_set_tally_mode", "lt_last_log_stages", "lt_reserve_log", "lt_render_surface_old", "lt_set_overlap", "lt_last_log_hot_tiles",
-    "lt_last_log_info", "lt_set_tally_quantity",
+    "lt_last_log_info", "lt_set_tally_quantity", "lt_set_tuning", "lt_mesh_accel_info", "lt_build_bvh",
 ]
 
 # lt_vertex as a NumPy record (112 bytes, same layout as the C struct)
@@ -41,6 +41,24 @@ VERTEX_LIGHT, VERTEX_REFLECTIVE, VERTEX_TRANSMISSIVE, VERTEX_VOLUME = 5, 3, 4, 7
 
 class LtError(RuntimeError):
     pass
+
+
+NODE_DTYPE = np.dtype([("lo", "<f8", 3), ("hi", "<f8", 3), ("offset", "<i4"), ("n_prims", "<i4"), ("axis", "<i4"), ("pad_", "<i4")])   # lt_bvh_node
+
+
+def build_bvh_arrays(verts, split_method=1):
+    """lt_build_bvh (host C++, no device): verts [T, 3, 3] -> (order [T] int32: ordered_prims[i] = input triangle order[i],
+    nodes: structured array of lt_bvh_node records in pre-order)."""
+    v = _f64(verts).reshape(-1, 3, 3)
+    T = v.shape[0]
+    order = np.empty(T, dtype=np.int32)
+    nodes = np.zeros(max(2 * T, 1), dtype=NODE_DTYPE)
+    nn = C.c_int(0)
+    rc = lib().lt_build_bvh(_dp(v), C.c_int(T), C.c_int(int(split_method)), _ip(order), nodes.ctypes.data_as(C.c_void_p),
+                            C.c_int(len(nodes)), C.byref(nn))
+    if rc:
+        raise LtError("lt_build_bvh failed (%d): needs >= 1 triangle with finite vertices and split_method 0 or 1" % rc)
+    return order, nodes[:nn.value]
 
 
 class Medium(C.Structure):
@@ -184,21 +202,22 @@ class Context:
                                      C.c_double(n_below)), "lt_set_layers")
 
     def set_mesh(self, verts, med_front, med_back, nodes):
+        """nodes: lt_bvh_node records -- a structured array (NODE_DTYPE, as build_bvh_arrays returns) or a dict of arrays
+        lo [N, 3], hi [N, 3], offset, n_prims, axis (as linear_bvh_arrays returns)."""
         v = _f64(verts).reshape(-1, 3, 3)
         mf = np.ascontiguousarray(med_front, dtype=np.int32)
         mb = np.ascontiguousarray(med_back, dtype=np.int32)
-        n = len(nodes["offset"])
-        arr = (BvhNode * max(n, 1))()
-        for i in range(n):
-            for k in range(3):
-                arr[i].lo[k] = float(nodes["lo"][i][k])
-                arr[i].hi[k] = float(nodes["hi"][i][k])
-            arr[i].offset = int(nodes["offset"][i])
-            arr[i].n_prims = int(nodes["n_prims"][i])
-            arr[i].axis = int(nodes["axis"][i])
+        if isinstance(nodes, np.ndarray) and nodes.dtype == NODE_DTYPE:
+            arr = np.ascontiguousarray(nodes)
+        else:       # packed with array assignments: a per-node Python loop costs ~0.2 s on a 20 000-node tree
+            n_ = len(nodes["offset"])
+            arr = np.zeros(n_, dtype=NODE_DTYPE)
+            arr["lo"] = np.asarray(nodes["lo"], dtype=np.float64).reshape(n_, 3); arr["hi"] = np.asarray(nodes["hi"], dtype=np.float64).reshape(n_, 3)
+            arr["offset"] = nodes["offset"]; arr["n_prims"] = nodes["n_prims"]; arr["axis"] = nodes["axis"]
+        n = len(arr)
         if mf.size != v.shape[0] or mb.size != v.shape[0]:
             raise LtError("set_mesh: medium arrays must have one entry per triangle")
-        self._ck(lib().lt_set_mesh(self._h, _dp(v), _ip(mf), _ip(mb), C.c_int(v.shape[0]), arr, C.c_int(n)),
+        self._ck(lib().lt_set_mesh(self._h, _dp(v), _ip(mf), _ip(mb), C.c_int(v.shape[0]), arr.ctypes.data_as(C.c_void_p), C.c_int(n)),
                  "lt_set_mesh")
 
     def set_grid(self, shape, origin, voxel, dtype="f64"):
@@ -224,6 +243,32 @@ class Context:
         w / mu_t, so that grid / (voxel volume x photons) IS the fluence, in heterogeneous media too (lt.h)."""
         q = {"absorbed": 0, "fluence": 1}.get(quantity, quantity)
         self._ck(lib().lt_set_tally_quantity(self._h, C.c_int(int(q))), "lt_set_tally_quantity")
+
+    def mesh_accel_info(self):
+        """dict(kind, march_dims, march_entries, clearance_dims) of the current mesh (lt.h: lt_mesh_accel_info)."""
+        kind, ent = C.c_int(0), C.c_uint64(0)
+        md, cd = (C.c_int * 3)(), (C.c_int * 3)()
+        self._ck(lib().lt_mesh_accel_info(self._h, C.byref(kind), md, C.byref(ent), cd), "lt_mesh_accel_info")
+        return dict(kind=kind.value, march_dims=tuple(md), march_entries=ent.value, clearance_dims=tuple(cd))
+
+    def set_tuning(self, key, value=-1):
+        """An experiment knob of the library (lt.h: lt_set_tuning); value < 0 (default) restores the built-in default."""
+        self._ck(lib().lt_set_tuning(self._h, key.encode(), C.c_int64(int(value))), "lt_set_tuning")
+
+    def tuning(self, **knobs):
+        """Context manager: the given knobs for the duration of the block, defaults restored afterwards."""
+        ctx = self
+
+        class _T:
+            def __enter__(self_):
+                for k, v in knobs.items():
+                    ctx.set_tuning(k, v)
+                return ctx
+
+            def __exit__(self_, *a):
+                for k in knobs:
+                    ctx.set_tuning(k, -1)
+        return _T()
 
     def set_launch_config(self, blocks_per_cu=0, threads_per_block=0):
         self._ck(lib().lt_set_launch_config(self._h, C.c_int(blocks_per_cu), C.c_int(threads_per_block)),

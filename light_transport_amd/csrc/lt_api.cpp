@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cctype>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -131,6 +132,26 @@ struct lt_ctx {
     bool dmap_valid = false, tile_cnt_ready = false, last_hot = false;
     uint32_t dmap_tiles = 0, dmap_bits2 = 0;      // the partition geometry the map was made for
     bool tables_dirty = true, media_dirty = false;
+    // Experiment knobs (lt_set_tuning; -1 = built-in default).  The environment variable LT_<KEY IN CAPITALS> seeds each of
+    // them ONCE, in lt_create: nothing in this library reads the environment after that.
+    struct Knobs {
+        long query_min = -1, log_bits2 = -1, log_hot = -1, overlap_walk_bpc = -1, diag_no_tally = -1, log_timing = -1,
+             march_cells = -1, march_scale_milli = -1, no_march = -1, no_clearance = -1, no_near_lists = -1,
+             clearance_cells = -1, march_info = -1;
+        std::string overlap_pattern;      // LT_OVERLAP_PATTERN (relative sub-batch sizes; tools/pattern_ab.py)
+    } knob;
+    long* knob_by_name(const char* key)
+    {
+        static const struct { const char* k; long Knobs::*m; } tab[] = {
+            {"query_min", &Knobs::query_min}, {"log_bits2", &Knobs::log_bits2}, {"log_hot", &Knobs::log_hot},
+            {"overlap_walk_bpc", &Knobs::overlap_walk_bpc}, {"diag_no_tally", &Knobs::diag_no_tally}, {"log_timing", &Knobs::log_timing},
+            {"march_cells", &Knobs::march_cells}, {"march_scale_milli", &Knobs::march_scale_milli}, {"no_march", &Knobs::no_march},
+            {"no_clearance", &Knobs::no_clearance}, {"no_near_lists", &Knobs::no_near_lists}, {"clearance_cells", &Knobs::clearance_cells},
+            {"march_info", &Knobs::march_info}};
+        for (const auto& t : tab) if (std::strcmp(key, t.k) == 0) return &(knob.*(t.m));
+        return nullptr;
+    }
+    bool on(long v) const { return v > 0; }
     bool timed = false;
 
     int fail(int code, const char* fmt, ...)
@@ -288,10 +309,10 @@ int build_march_grid(lt_ctx* c)
     }
     std::nth_element(size.begin(), size.begin() + nt / 2, size.end());
     double h = size[nt / 2];
-    if (const char* e = std::getenv("LT_MARCH_SCALE")) { const double v = std::atof(e); if (v > 0.01 && v < 100) h *= v; }
+    if (c->knob.march_scale_milli > 10 && c->knob.march_scale_milli < 100000) h *= 1e-3 * (double)c->knob.march_scale_milli;
     int per_axis = h > 0 ? (int)std::lround(longest / h) : 256;
     per_axis = per_axis < 32 ? 32 : (per_axis > 256 ? 256 : per_axis);
-    if (const char* e = std::getenv("LT_MARCH_CELLS")) { const int v = std::atoi(e); if (v >= 4 && v <= 512) per_axis = v; }
+    if (c->knob.march_cells >= 4 && c->knob.march_cells <= 512) per_axis = (int)c->knob.march_cells;
     h = longest / (double)per_axis;
     MarchGrid& G = c->mgrid;
     int n[3];
@@ -351,7 +372,7 @@ int build_march_grid(lt_ctx* c)
                                       (double*)c->d_mcoarse.p, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));      // rec / list are pageable host memory
     c->have_march = true;
-    if (std::getenv("LT_MARCH_INFO"))
+    if (c->on(c->knob.march_info))
         std::fprintf(stderr, "[lt march] %zu triangles, grid %d x %d x %d (cell %.4g), %zu list entries (%.2f per triangle), %zu cells listed\n",
                      nt, n[0], n[1], n[2], h, pairs.size(), (double)pairs.size() / (double)nt,
                      (size_t)std::count_if(count.begin(), count.end(), [](uint32_t v) { return v != 0; }));
@@ -399,10 +420,13 @@ int upload_tables(lt_ctx* c)
         vq.f32 = 1;
         const bool lds32 = walk_lds_bytes(vq, nm, 0, ntr, nno) <= kMeshLdsBudget;
         c->have_march = false;
-        if (!lds64 && !std::getenv("LT_NO_CLEARANCE") && !std::getenv("LT_NO_MARCH")) { if ((rc = build_march_grid(c))) return rc; }
+        if (!lds64 && !c->on(c->knob.no_clearance) && !c->on(c->knob.no_march)) { if ((rc = build_march_grid(c))) return rc; }
         // clearance grid over the root bounds: 64 cells along the longest axis (LT_NO_CLEARANCE=1 disables it)
         c->have_clear = false;
-        if (!std::getenv("LT_NO_CLEARANCE") && (lds32 || !c->have_march)) {
+        // (only for meshes some walk variant stages in LDS: the f64-beyond-LDS kernels use the march grid or the plain BVH,
+        // and the builder below is brute force over cells x triangles with 16-bit triangle ids in its records)
+        if (!c->on(c->knob.no_clearance) && lds32) {
+            if (t64.size() > 0xffff) return c->fail(LT_E_UNSUPPORTED, "lt_set_mesh: %zu triangles within the LDS budget cannot be (near-triangle ids are 16 bits)", t64.size());
             double ext[3], longest = 0;
             for (int k = 0; k < 3; k++) { ext[k] = c->nodes[0].hi[k] - c->nodes[0].lo[k]; if (ext[k] > longest) longest = ext[k]; }
             if (longest > 0 && std::isfinite(longest)) {
@@ -411,7 +435,7 @@ int upload_tables(lt_ctx* c)
                 int per_axis = (int)std::cbrt(2.0e9 / (double)(t64.empty() ? 1 : t64.size()));
                 per_axis = per_axis < 32 ? 32 : (per_axis > 128 ? 128 : per_axis);
                 // LT_CLEARANCE_CELLS overrides (tuning experiments)
-                if (const char* e = std::getenv("LT_CLEARANCE_CELLS")) { int v = std::atoi(e); if (v >= 8 && v <= 512) per_axis = v; }
+                if (c->knob.clearance_cells >= 8 && c->knob.clearance_cells <= 512) per_axis = (int)c->knob.clearance_cells;
                 const double h = longest / (double)per_axis;
                 for (int k = 0; k < 3; k++) {
                     c->cn[k] = (int)std::ceil(ext[k] / h); if (c->cn[k] < 1) c->cn[k] = 1;
@@ -421,7 +445,7 @@ int upload_tables(lt_ctx* c)
                 // 16 bytes per cell: the clearance and the cell's nearest triangles (WalkParams::clear; LT_NO_NEAR_LISTS=1
                 // leaves the lists empty, every query then walks the BVH)
                 HIP_TRY(c, c->d_clear.ensure(cells * 16));
-                HIP_TRY(c, launch_build_clearance(c->d_tris[0].p, (int)t64.size(), std::getenv("LT_NO_NEAR_LISTS") ? 0 : 1, c->d_clear.p,
+                HIP_TRY(c, launch_build_clearance(c->d_tris[0].p, (int)t64.size(), c->on(c->knob.no_near_lists) ? 0 : 1, c->d_clear.p,
                                                   c->cn[0], c->cn[1], c->cn[2], c->corg, c->ccell, c->stream));
                 c->have_clear = true;
             }
@@ -469,7 +493,7 @@ LogGeom log_geom(const lt_ctx* c)
     // two passes over digits of <= 7 bits each (<= 1024 level-1 bins).
     uint32_t b = 0;
     if (g.n_tiles > 1024) { b = 1; while ((1u << (2 * b)) < g.n_tiles && b < 7) b++; }
-    if (const char* e = std::getenv("LT_LOG_BITS2")) { int v = std::atoi(e); b = v < 0 ? 0u : (v > 7 ? 7u : (uint32_t)v); }
+    if (c->knob.log_bits2 >= 0) b = c->knob.log_bits2 > 7 ? 7u : (uint32_t)c->knob.log_bits2;
     while ((g.n_tiles >> b) > 1024 && b < 7) b++;
     g.bits2 = b;
     g.nb1 = b ? (g.n_tiles + (1u << b) - 1) >> b : g.n_tiles;
@@ -534,7 +558,14 @@ int plan_log(lt_ctx* c, uint64_t n, int lanes, LogPlan* plan)
     size_t per_lane = c->log_budget / (2 * rec_bytes) / (size_t)lanes;     // the budget covers log + ping-pong copy of every lane
     if (per_lane > 0xFF000000ull) per_lane = 0xFF000000ull;                // 32-bit record offsets
     per_lane = (per_lane / kLogChunk) * kLogChunk;
-    if (per_lane < 16 * (size_t)kLogChunk) return c->fail(LT_E_INVALID, "lt_launch: log budget too small (%zu bytes)", c->log_budget);
+    if (per_lane < 16 * (size_t)kLogChunk) {
+        if (lanes > 1) return LT_E_NOMEM;      // the budget does not stretch to this many lanes: the caller retries with fewer
+        return c->fail(LT_E_INVALID, "lt_launch: log budget too small (%zu bytes)", c->log_budget);
+    }
+    // lanes 1, 2 tally into grids of their own (run_log_plan): allocated HERE, so that a device without room for them
+    // falls back to fewer lanes like a device without room for the logs
+    for (int l = 1; l < lanes; l++)
+        if (c->d_gridx[l - 1].ensure(c->n_vox() * c->grid_elem()) != hipSuccess) { (void)hipGetLastError(); return LT_E_NOMEM; }
     // no measurement yet (pilot or tiny launch): tissue-like media give 100-400 records per photon
     const double rate = c->rec_per_photon > 0.0 ? c->rec_per_photon : 400.0;
     // Overlapped launches: every lane starts with one large batch (the walks run side by side at full occupancy), then
@@ -574,7 +605,7 @@ int plan_log(lt_ctx* c, uint64_t n, int lanes, LogPlan* plan)
         while (left > 0) { const uint64_t b = (double)left > fit ? (uint64_t)fit : left; plan->batches.emplace_back(0, b); left -= b; }
     } else {
         int l = 0;
-        if (const char* e = std::getenv("LT_OVERLAP_PATTERN")) {
+        if (const char* e = c->knob.overlap_pattern.empty() ? nullptr : c->knob.overlap_pattern.c_str()) {
             std::vector<double> wts; double sum = 0.0;
             for (const char* q = e; *q;) { char* end = nullptr; const double v_ = std::strtod(q, &end); if (end == q) break; if (v_ > 0) { wts.push_back(v_); sum += v_; } q = *end ? end + 1 : end; }
             for (size_t k = 0; k < wts.size() && left > 0 && sum > 0; k++) {
@@ -654,7 +685,7 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
     // two lanes: each walk takes half of the resident workgroups, so that two walks together fill the register file
     // and one walk leaves room for the other lane's partition / reduce workgroups
     int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (plan.lanes >= 2 ? (resident + 1) / 2 : resident);
-    if (plan.lanes >= 2) if (const char* e = std::getenv("LT_OVERLAP_WALK_BPC")) { int v_ = std::atoi(e); if (v_ >= 1 && v_ <= 8) per_cu = v_; }
+    if (plan.lanes >= 2 && c->knob.overlap_walk_bpc >= 1 && c->knob.overlap_walk_bpc <= 8) per_cu = (int)c->knob.overlap_walk_bpc;
     const unsigned long long cap = (unsigned long long)per_cu * (unsigned long long)c->prop.multiProcessorCount;
     if (plan.lanes >= 2) {
         // lanes 1, 2 tally into grids of their own (zeroed here, added to the ctx grid at the join): every lane can then
@@ -664,8 +695,7 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
         for (int l = 1; l < plan.lanes; l++) {
             if (!c->lanes[l].stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->lanes[l].stream, hipStreamNonBlocking));
-            HIP_TRY(c, c->d_gridx[l - 1].ensure(gb));
-            HIP_TRY(c, hipStreamWaitEvent(c->lanes[l].stream, c->ev_fork, 0));
+            HIP_TRY(c, hipStreamWaitEvent(c->lanes[l].stream, c->ev_fork, 0));      // (d_gridx: allocated by plan_log)
             HIP_TRY(c, hipMemsetAsync(c->d_gridx[l - 1].p, 0, gb, c->lanes[l].stream));
         }
     }
@@ -732,20 +762,26 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
     return LT_OK;
 }
 
-// depth of the flattened tree (bounds the traversal stack) + structural checks
-int bvh_depth(const std::vector<lt_bvh_node>& n, int n_tris, int idx, int depth, int* max_depth, int* visited)
+// structural check of a flattened pre-order tree: every node reached exactly once, leaves within the triangle range,
+// interior nodes with a valid axis and a second child behind the first subtree.  Iterative: the traversal on the device is
+// stackless (skip links), so there is no depth a tree could exceed.
+bool bvh_is_valid(const std::vector<lt_bvh_node>& n, int n_tris, int* max_depth)
 {
-    if (idx < 0 || idx >= (int)n.size() || depth > 64) return -1;
-    (*visited)++;
-    if (depth > *max_depth) *max_depth = depth;
-    const lt_bvh_node& nd = n[idx];
-    if (nd.n_prims > 0) {
-        if (nd.offset < 0 || nd.offset + nd.n_prims > n_tris) return -1;
-        return 0;
+    std::vector<std::pair<int, int>> todo{{0, 0}};     // (node, depth)
+    std::vector<char> seen(n.size(), 0);
+    size_t visited = 0;
+    *max_depth = 0;
+    while (!todo.empty()) {
+        const auto [idx, depth] = todo.back(); todo.pop_back();
+        if (idx < 0 || idx >= (int)n.size() || seen[idx]) return false;
+        seen[idx] = 1; visited++;
+        if (depth > *max_depth) *max_depth = depth;
+        const lt_bvh_node& nd = n[idx];
+        if (nd.n_prims > 0) { if (nd.offset < 0 || nd.offset + nd.n_prims > n_tris) return false; continue; }
+        if (nd.axis < 0 || nd.axis > 2 || nd.offset <= idx + 1) return false;
+        todo.emplace_back(nd.offset, depth + 1); todo.emplace_back(idx + 1, depth + 1);
     }
-    if (nd.axis < 0 || nd.axis > 2 || nd.offset <= idx + 1) return -1;
-    if (bvh_depth(n, n_tris, idx + 1, depth + 1, max_depth, visited)) return -1;
-    return bvh_depth(n, n_tris, nd.offset, depth + 1, max_depth, visited);
+    return visited == n.size();
 }
 
 }  // namespace
@@ -760,10 +796,6 @@ int lt_create(lt_ctx** out, int device_id)
 {
     if (!out) return LT_E_INVALID;
     *out = nullptr;
-    // A launch may use two streams (lt_set_overlap).  The HIP runtime multiplexes a process's streams onto
-    // GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue are serialised.  Eight queues keep the
-    // lanes apart when torch / RCCL streams exist in the same process.  Only effective if the runtime has not started yet.
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev <= 0) {
@@ -775,6 +807,16 @@ int lt_create(lt_ctx** out, int device_id)
     lt_ctx* c = new (std::nothrow) lt_ctx();
     if (!c) { g_create_error = "out of host memory"; return LT_E_NOMEM; }
     c->device = device_id;
+    {   // the one place the environment is read: LT_QUERY_MIN, LT_LOG_HOT, ... seed the knobs of lt_set_tuning
+        static const char* const names[] = {"query_min", "log_bits2", "log_hot", "overlap_walk_bpc", "diag_no_tally", "log_timing", "march_cells",
+                                            "march_scale_milli", "no_march", "no_clearance", "no_near_lists", "clearance_cells", "march_info"};
+        for (const char* k : names) {
+            std::string name = "LT_";
+            for (const char* q = k; *q; q++) name += (char)std::toupper((unsigned char)*q);
+            if (const char* v = std::getenv(name.c_str())) *c->knob_by_name(k) = std::atol(v);
+        }
+        if (const char* v = std::getenv("LT_OVERLAP_PATTERN")) c->knob.overlap_pattern = v;
+    }
     e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipGetDeviceProperties(&c->prop, device_id);
     if (e == hipSuccess && std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
@@ -877,10 +919,9 @@ int lt_set_mesh(lt_ctx* c, const double* verts, const int32_t* med_front, const 
     for (size_t i = 0; i < (size_t)n_tris * 9; i++)
         if (!std::isfinite(verts[i])) return c->fail(LT_E_INVALID, "lt_set_mesh: non-finite vertex");
     std::vector<lt_bvh_node> nn(nodes, nodes + n_nodes);
-    int depth = 0, visited = 0;
-    if (bvh_depth(nn, n_tris, 0, 0, &depth, &visited) != 0 || visited != n_nodes)
+    int depth = 0;
+    if (!bvh_is_valid(nn, n_tris, &depth))
         return c->fail(LT_E_INVALID, "lt_set_mesh: BVH is not a valid pre-order tree over %d triangles", n_tris);
-    if (depth >= 31) return c->fail(LT_E_UNSUPPORTED, "lt_set_mesh: BVH depth %d exceeds the traversal stack (31)", depth);
     size_t covered = 0;
     for (const auto& nd : nn) if (nd.n_prims > 0) covered += (size_t)nd.n_prims;
     if (covered != (size_t)n_tris) return c->fail(LT_E_INVALID, "lt_set_mesh: leaves cover %zu of %d triangles", covered, n_tris);
@@ -935,6 +976,17 @@ int lt_set_max_steps(lt_ctx* c, uint32_t max_steps)
     return LT_OK;
 }
 
+int lt_set_tuning(lt_ctx* c, const char* key, int64_t value)
+{
+    CHECK_CTX(c);
+    long* k = key ? c->knob_by_name(key) : nullptr;
+    if (!k) return c->fail(LT_E_INVALID, "lt_set_tuning: unknown key '%s'", key ? key : "(null)");
+    *k = value < 0 ? -1 : (long)value;
+    // knobs that shape the hot-tile map or the partition geometry: the map of the current scene is made again
+    if (!std::strcmp(key, "log_hot") || !std::strcmp(key, "log_bits2")) { c->dmap_valid = false; }
+    return LT_OK;
+}
+
 int lt_set_tally_quantity(lt_ctx* c, int quantity)
 {
     CHECK_CTX(c);
@@ -986,7 +1038,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     v.tally = c->tally;
     v.capture = c->max_vertices > 0 ? 1 : 0;
     if (v.capture && (v.f32 || v.table)) return c->fail(LT_E_UNSUPPORTED, "lt_launch: vertex capture runs the f64 walk with the XORWOW generator");
-    if (std::getenv("LT_DIAG_NO_TALLY")) v.tally = 3;  // diagnostic: time the walk without deposition
+    if (c->on(c->knob.diag_no_tally)) v.tally = 3;  // diagnostic: time the walk without deposition
     if (v.table && v.f32) return c->fail(LT_E_UNSUPPORTED, "lt_launch: table RNG runs the f64 walk only");
     if (v.table && v.tally == LT_TALLY_F32) return c->fail(LT_E_UNSUPPORTED, "lt_launch: table RNG needs an f64 or u64fx tally");
     if (v.table && table_steps == 0) return c->fail(LT_E_INVALID, "lt_launch: table_steps == 0");
@@ -1024,7 +1076,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     P.table = (const double*)c->d_table.p; P.table_steps = table_steps;
     P.max_steps = c->max_steps;
     P.counters = (DevCounters*)c->d_counters.p;
-    if (const char* e = std::getenv("LT_QUERY_MIN")) { const int v_ = std::atoi(e); if (v_ >= 1 && v_ <= 64) P.query_min = (unsigned)v_; }
+    if (c->knob.query_min >= 1 && c->knob.query_min <= 64) P.query_min = (unsigned)c->knob.query_min;
     if (c->have_mesh && c->have_clear) {
         P.clear = (const uint4*)c->d_clear.p; P.cnx = c->cn[0]; P.cny = c->cn[1]; P.cnz = c->cn[2];
         for (int k = 0; k < 3; k++) { P.corg[k] = c->corg[k]; P.cinv[k] = 1.0 / c->ccell[k]; }
@@ -1066,7 +1118,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     const int mode = c->tally_mode == 2 ? 1 : c->tally_mode;
     { int rc3 = collect_log_stats(c); if (rc3) return rc3; }   // stats of the previous launch size this one
     LogGeom G = log_geom(c);
-    bool use_log = mode == 1 && !v.table && c->max_vertices == 0 && G.n_tiles <= kMaxLogTiles && !std::getenv("LT_DIAG_NO_TALLY");
+    bool use_log = mode == 1 && !v.table && c->max_vertices == 0 && G.n_tiles <= kMaxLogTiles && !c->on(c->knob.diag_no_tally);
     if (use_log) {
         LogRun R;
         R.c = c; R.P = P; R.v = v; R.cfg = cfg; R.G = G;
@@ -1094,7 +1146,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
             // two-pass grid with a measured tile histogram (the pilot's, or an earlier small launch's): make the
             // hot-tile map for this scene.  LT_LOG_HOT caps the number of hot tiles (0: plain two-pass form).
             uint32_t max_hot = log_max_digits() - G.nb1;
-            if (const char* e = std::getenv("LT_LOG_HOT")) { const long v_ = std::atol(e); if (v_ >= 0 && (uint32_t)v_ < max_hot) max_hot = (uint32_t)v_; }
+            if (c->knob.log_hot >= 0 && (uint32_t)c->knob.log_hot < max_hot) max_hot = (uint32_t)c->knob.log_hot;
             if (max_hot > 0) {
                 HIP_TRY(c, c->d_dmap.ensure(((size_t)G.n_tiles + 2) * sizeof(uint16_t)));
                 HIP_TRY(c, c->d_dmeta.ensure(4 * sizeof(uint32_t)));
@@ -1107,7 +1159,10 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
             int lanes = choose_lanes(c, n_photons - done);
             LogPlan plan;
             rc = plan_log(c, n_photons - done, lanes, &plan);
-            while (rc == LT_E_NOMEM && lanes > 1) { lanes--; rc = plan_log(c, n_photons - done, lanes, &plan); }
+            while (rc == LT_E_NOMEM && lanes > 1) {
+                lanes--; rc = plan_log(c, n_photons - done, lanes, &plan);
+                if (c->auto_pending >= 0) c->auto_pending = lanes - 1;      // what this launch measures is the regime it really runs in
+            }
             if (rc == LT_E_NOMEM) { use_log = false; rc = LT_OK; }
             else if (rc) return rc;
             else {
@@ -1119,7 +1174,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
                 c->log_stats_pending = true; c->pending_photons = n_photons;   // the job counters hold the pilot's records too
                 if (c->auto_pending >= 0 && done > 0) c->auto_pending = -1;     // (first launch of a scene: not a clean measurement)
                 c->timed = true;
-                if (std::getenv("LT_LOG_TIMING")) {   // diagnostic: per-stage device times of this launch (synchronises)
+                if (c->on(c->knob.log_timing)) {   // diagnostic: per-stage device times of this launch (synchronises)
                     double ms[4]; uint64_t rec = 0, bat = 0;
                     if (lt_last_log_stages(c, ms, &rec, &bat) == LT_OK)
                         std::fprintf(stderr, "[lt log] %llu photons, %d lane(s), %llu batches, %llu records (%.1f / photon), %llu to atomics; "
@@ -1595,6 +1650,21 @@ int lt_render_surface_old(lt_ctx* c, int width, int height, int samples, int max
 {
     return render_impl(c, 1, choices_per_sample, width, height, samples, max_depth, camera, f_distance, xs, ys, rand_0,
                        rand_1, light_choice, image);
+}
+
+int lt_mesh_accel_info(lt_ctx* c, int* kind, int march_dims[3], uint64_t* march_entries, int clearance_dims[3])
+{
+    CHECK_CTX(c);
+    if (!c->have_mesh) return c->fail(LT_E_STATE, "lt_mesh_accel_info: lt_set_mesh first");
+    BIND(c);
+    if (c->media.empty()) { lt_medium m = {0, 0, 0, 1}; c->media.push_back(m); }
+    int rc = upload_tables(c);
+    if (rc) return rc;
+    if (kind) *kind = (c->have_clear ? 1 : 0) | (c->have_march ? 2 : 0);
+    if (march_dims) { march_dims[0] = c->have_march ? c->mgrid.nx : 0; march_dims[1] = c->have_march ? c->mgrid.ny : 0; march_dims[2] = c->have_march ? c->mgrid.nz : 0; }
+    if (march_entries) *march_entries = c->have_march ? (uint64_t)c->march_entries : 0;
+    if (clearance_dims) for (int k = 0; k < 3; k++) clearance_dims[k] = c->have_clear ? c->cn[k] : 0;
+    return LT_OK;
 }
 
 int lt_device_info(lt_ctx* c, char* name, size_t name_len, int* n_cus, int* clock_mhz, size_t* hbm_bytes)

@@ -860,6 +860,7 @@ LT_DEV void record_vertex(const WalkParams& P, unsigned long long rel, unsigned&
 // global atomic.  Log mode: the wave's records are compacted by ballot rank and appended, coalesced, to the wave's
 // current log chunk (SoA: voxel index, value); a chunk is claimed with one returning atomic per kLogChunk records.
 // If the log is exhausted the wave falls back to atomics, so a too-small log costs speed, never correctness.
+constexpr unsigned kLogExhausted = 0xfffffffeu;   // lg_chunk: this wave has found the log full (0xffffffff: no chunk claimed yet)
 template <int TALLY>
 LT_DEV void emit_deposit(const WalkParams& P, bool has, unsigned idx, typename TallyT<TALLY>::type val,
                          unsigned& lg_cur, unsigned& lg_end, unsigned& lg_chunk, uint32_t* s_hist)
@@ -872,17 +873,20 @@ LT_DEV void emit_deposit(const WalkParams& P, bool has, unsigned idx, typename T
     const unsigned long long m = __ballot(has);
     if (m == 0ull) return;
     const unsigned cnt = (unsigned)__popcll(m);
-    if (lg_end - lg_cur < cnt) {
+    // (a wave that has found the log exhausted does not ask again: lg_chunk == kLogExhausted is sticky, so an undersized log
+    // costs each wave ONE extra returning atomic, not one per emit on 16 shared addresses, and the group counters stay
+    // within cap + resident waves -- far from wrapping grp + kLogGroups * c)
+    if (lg_chunk != kLogExhausted && lg_end - lg_cur < cnt) {
         const int lane = threadIdx.x & 63;
         const unsigned grp = blockIdx.x & (kLogGroups - 1);
-        if (lg_chunk != 0xffffffffu && lane == 0) P.log_fill[lg_chunk] = lg_cur - lg_chunk * kLogChunk;
+        if (lg_chunk < kLogExhausted && lane == 0) P.log_fill[lg_chunk] = lg_cur - lg_chunk * kLogChunk;
         unsigned c = 0;
         if (lane == 0) c = __hip_atomic_fetch_add(P.log_next + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c = grp + kLogGroups * __builtin_amdgcn_readfirstlane(c);     // the group's own chunks: see kLogGroups
         if (c < P.log_cap_chunks) { lg_chunk = c; lg_cur = c * kLogChunk; lg_end = lg_cur + kLogChunk; }
-        else { lg_chunk = 0xffffffffu; lg_cur = lg_end = 0; }
+        else { lg_chunk = kLogExhausted; lg_cur = lg_end = 0; }
     }
-    if (lg_chunk == 0xffffffffu) {  // log exhausted: back to the linear voxel index and a global atomic
+    if (lg_chunk == kLogExhausted) {  // log exhausted: back to the linear voxel index and a global atomic
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(P.log_overflow, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (has) {
             const unsigned tile = idx >> kTileShift, tx = tile % P.log_ntx, ty = (tile / P.log_ntx) % P.log_nty,
@@ -1276,7 +1280,7 @@ __global__ void k_build_clearance(const TriD<double>* tris, int n_tris, int near
     if ((double)f > c0 && f > 0) f = __uint_as_float(__float_as_uint(f) - 1u);      // round toward zero
     if (c0 == inf) f = 3.0e38f;
     unsigned y = 0, z = 0xffffffffu, w = 0xffffffffu;
-    if (near_lists && n_tris <= 0xffff) {
+    if (near_lists) {      // (ids are 16 bits: the host builds these records only for meshes whose tables fit LDS, <= ~1100 triangles, and refuses otherwise)
         y = half_down(bound(best[2])) | (half_down(bound(best[4])) << 16);
         z = (unsigned)(id[0] & 0xffff) | ((unsigned)(id[1] & 0xffff) << 16);      // (-1 & 0xffff = 0xffff: none)
         w = (unsigned)(id[2] & 0xffff) | ((unsigned)(id[3] & 0xffff) << 16);

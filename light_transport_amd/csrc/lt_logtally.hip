@@ -602,16 +602,21 @@ hipError_t launch_log_plan(const uint32_t* tile_cnt, uint32_t n_tiles, uint32_t 
 
 // persistent grids: as many workgroups as are resident at once (occupancy query x CUs); the result is cached per
 // kernel (a benign race: every thread computes the same number)
-static unsigned persistent_blocks(std::atomic<unsigned>& cache, const void* fn, int threads, size_t lds)
+constexpr int kMaxDevices = 16;      // occupancy of a kernel is cached per device: a process may drive GPUs that differ (lt_create takes a device id)
+struct BlockCache { std::atomic<unsigned> per_dev[kMaxDevices]; };
+static unsigned persistent_blocks(BlockCache& cache, const void* fn, int threads, size_t lds)
 {
-    unsigned b = cache.load(std::memory_order_relaxed);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    std::atomic<unsigned>* slot = dev < kMaxDevices ? &cache.per_dev[dev] : nullptr;      // (beyond that: ask every time)
+    unsigned b = slot ? slot->load(std::memory_order_relaxed) : 0u;
     if (b) return b;
-    int per_cu = 0, dev = 0, cus = 256;
+    int per_cu = 0, cus = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     b = (unsigned)(per_cu * cus);
-    cache.store(b, std::memory_order_relaxed);
+    if (slot) slot->store(b, std::memory_order_relaxed);
     return b;
 }
 
@@ -628,7 +633,7 @@ template <typename TV, int PASS, bool HOT> static hipError_t launch_part_t(const
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    static std::atomic<unsigned> blocks{0};   // per instantiation
+    static BlockCache blocks{};   // per instantiation
     hipLaunchKernelGGL((k_log_part<TV, PASS, HOT>), dim3(persistent_blocks(blocks, fn, kPartThreads, lds)), dim3(kPartThreads), lds, s, L);
     return hipGetLastError();
 }
@@ -651,7 +656,7 @@ hipError_t launch_log_count1(const LogReduceParams& L, hipStream_t s)
     if (!L.dmap || L.bits2 == 0 || L.n_tiles > kMaxHotTiles) return hipErrorInvalidValue;
     const size_t lds = (size_t)kMaxBins * sizeof(uint32_t) + kMapLds;
     const void* fn = reinterpret_cast<const void*>(&k_log_count1);
-    static std::atomic<unsigned> blocks{0};
+    static BlockCache blocks{};
     const unsigned b = persistent_blocks(blocks, fn, kPartThreads, lds) / kLogGroups * kLogGroups;   // a workgroup serves one group
     hipLaunchKernelGGL(k_log_count1, dim3(b < kLogGroups ? kLogGroups : b), dim3(kPartThreads), lds, s, L);
     return hipGetLastError();
@@ -663,7 +668,7 @@ hipError_t launch_log_part2(const LogReduceParams& L, hipStream_t s)
     hipLaunchKernelGGL(k_log_items2, dim3(256), dim3(256), 0, s, L);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    static std::atomic<unsigned> blocks{0};
+    static BlockCache blocks{};
     const void* fn = reinterpret_cast<const void*>(&k_log_count2);
     hipLaunchKernelGGL(k_log_count2, dim3(persistent_blocks(blocks, fn, kPartThreads, 0)), dim3(kPartThreads), 0, s, L);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -679,7 +684,7 @@ template <typename TV> static hipError_t launch_reduce_t(const LogReduceParams& 
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    static std::atomic<unsigned> blocks{0};
+    static BlockCache blocks{};
     hipLaunchKernelGGL(k_log_reduce<TV>, dim3(persistent_blocks(blocks, fn, kReduceThreads, lds)), dim3(kReduceThreads), lds, s, L);
     return hipGetLastError();
 }

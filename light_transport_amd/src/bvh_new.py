@@ -185,17 +185,70 @@ def flatten_bvh(linear_nodes, node, offset):
 
 
 def build_linear_bvh(primitives, split_method=1):
-    """Convenience: the notebook's cells 19-22 in one call.
-    Returns (ordered_prims, linear_bvh)."""
-    boxes = [BoundedBox(p, i) for i, p in enumerate(primitives)]
-    root, boxes, ordered, total = build_bvh(primitives, boxes, 0, len(boxes), [], 0, split_method)
-    linear, used = flatten_bvh([LinearBVHNode() for _ in range(total)], root, 0)
-    assert used == total
-    return ordered, linear
+    """Convenience: the notebook's cells 19-22 in one call.  Returns (ordered_prims, linear_bvh).
+    The tree is built by the library's host builder (lt_build_bvh, C++: milliseconds where the recursion above takes
+    seconds on the reference's 10 000-triangle pumpkin) and handed back as LinearBVHNode objects; it equals
+    build_bvh + flatten_bvh above node for node (tests/test_host_api.py), so either route gives the same ordered_prims."""
+    from .._lib import build_bvh_arrays
+    if not len(primitives):
+        return [], []
+    order, nodes = build_bvh_arrays(triangles_array(primitives), split_method)
+    return [primitives[int(i)] for i in order], _LinearBVH(nodes)
+
+
+class _Bounds:
+    """AABB view of a flattened node (min_point / max_point / centroid, the fields the reference's AABB has)."""
+    __slots__ = ("min_point", "max_point")
+
+    def __init__(self, lo, hi):
+        self.min_point, self.max_point = lo, hi
+
+    @property
+    def centroid(self):
+        return (self.min_point + self.max_point) / 2
+
+
+class _LinearBVH:
+    """What build_linear_bvh returns in place of the reference's list of LinearBVHNode: the same sequence (len, indexing,
+    iteration yield LinearBVHNode objects with bounds / primitives_offset / second_child_offset / n_primitives / axis),
+    materialised on demand from the packed lt_bvh_node records of the host builder -- a 20 000-node tree is handed to
+    lt_set_mesh as one buffer, and nobody pays for 20 000 Python objects unless they look at them."""
+
+    def __init__(self, records):
+        self.records = records
+
+    def __len__(self):
+        return len(self.records)
+
+    def _node(self, i):
+        r = self.records[i]
+        nd = LinearBVHNode()
+        nd.bounds = _Bounds(r["lo"], r["hi"])
+        nd.n_primitives = int(r["n_prims"])
+        if nd.n_primitives > 0:
+            nd.primitives_offset = int(r["offset"])
+        else:
+            nd.second_child_offset, nd.axis = int(r["offset"]), int(r["axis"])
+        return nd
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._node(k) for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self._node(i)
+
+    def __iter__(self):
+        return (self._node(i) for i in range(len(self)))
 
 
 def linear_bvh_arrays(linear_bvh):
     """Pack LinearBVHNode objects into the arrays the C ABI takes (lt_bvh_node)."""
+    if isinstance(linear_bvh, _LinearBVH):
+        r = linear_bvh.records
+        return dict(lo=r["lo"].copy(), hi=r["hi"].copy(), offset=r["offset"].copy(), n_prims=r["n_prims"].copy(), axis=r["axis"].copy())
     n = len(linear_bvh)
     out = dict(lo=np.zeros((n, 3)), hi=np.zeros((n, 3)), offset=np.zeros(n, np.int32),
                n_prims=np.zeros(n, np.int32), axis=np.zeros(n, np.int32))

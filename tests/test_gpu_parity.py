@@ -512,12 +512,79 @@ def test_large_mesh_in_global_memory(ctx):
     assert c["w_escaped_mesh"] > 0 and fx.sum() > 0
 
 
+def test_integration_md_stub_runs_as_written(ctx):
+    """INTEGRATION.md shows the ctypes stub a maintainer would put into the reference's empty src/photon_tracing.py.  It
+    is documentation that claims to work: extract the FIRST python block verbatim, point its CDLL at the built library,
+    execute it, and hold its result against the package's own trace_photons on the same problem -- the same photons
+    (seed, ids) through the same kernels, so the f64 grids agree to summation order and the step counts exactly."""
+    import re
+    import light_transport_amd as lt
+    from light_transport_amd.src import photon_tracing as PT
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    assert "def trace_photons(" in block and 'C.CDLL("liblt_hip.so")' in block
+    ns = {}
+    exec(compile(block.replace('C.CDLL("liblt_hip.so")', "C.CDLL(%r)" % lt.LIB_PATH), "INTEGRATION.md", "exec"), ns)
+    media = [(0.43, 10.7, 0.79, 1.5), (0.27, 18.7, 0.82, 1.4)]
+    n, shape, origin, voxel = 50000, (32, 32, 32), (-3.2, -3.2, 0.0), (0.2, 0.2, 0.2)
+    got = ns["trace_photons"](media, [0.0, 0.1, np.inf], n, 7, shape, origin, voxel)
+    slab = PT.LayeredSlab([PT.OpticalMedium(*m) for m in media], [0.1, np.inf])
+    want, c = PT.trace_photons(slab, None, None, n, seed=7, grid=PT.VoxelGrid(shape, origin, voxel), source=PT.PencilBeam((0, 0, 0), (0, 0, 1)),
+                               return_counters=True)
+    assert got.shape == want.shape == (32, 32, 32) and got.sum() > 0.3 * n
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
+    assert abs(got.sum() - c["w_absorbed"]) < 1e-9 * n
+
+
+def test_deep_bvh_is_accepted(ctx):
+    """A flattened tree far deeper than 31 levels (a chain: every interior node splits one triangle off) is a valid input:
+    the device traversal is stackless.  (Rounds 1-2 rejected depth >= 31 'exceeds the traversal stack'.)"""
+    rs = np.random.RandomState(5)
+    T = 60
+    verts = np.zeros((T, 3, 3))
+    for k in range(T):
+        c = np.array([0.3 * k, 0.0, 0.0])
+        verts[k] = c + rs.uniform(-0.12, 0.12, size=(3, 3))
+    lo, hi = verts.min(axis=1), verts.max(axis=1)
+    N = 2 * T - 1                       # pre-order: interior i at 2i, its leaf (triangle i) at 2i + 1, the rest behind it
+    nodes = dict(lo=np.zeros((N, 3)), hi=np.zeros((N, 3)), offset=np.zeros(N, np.int32), n_prims=np.zeros(N, np.int32),
+                 axis=np.zeros(N, np.int32))
+    for i in range(T - 1):
+        nodes["lo"][2 * i], nodes["hi"][2 * i] = lo[i:].min(axis=0), hi[i:].max(axis=0)
+        nodes["offset"][2 * i] = 2 * i + 2                                  # second child
+        nodes["lo"][2 * i + 1], nodes["hi"][2 * i + 1] = lo[i], hi[i]
+        nodes["offset"][2 * i + 1], nodes["n_prims"][2 * i + 1] = i, 1
+    nodes["lo"][N - 1], nodes["hi"][N - 1] = lo[T - 1], hi[T - 1]
+    nodes["offset"][N - 1], nodes["n_prims"][N - 1] = T - 1, 1
+    none = -np.ones(T, np.int32)
+    ctx.set_mesh(verts, none, none, nodes)          # depth 59
+    ctx._mesh_key = None
+    n = 20000
+    # rays aimed at (or just past) random points of random triangles, from origins around the chain: most hit, many cross
+    # the boxes of several links, a quarter run nearly along the chain's axis (every level of the tree is entered)
+    o = rs.uniform(-1, 0.3 * T + 1, size=(n, 3)) * [1, 0, 0] + rs.uniform(-1, 1, size=(n, 3)) * [0, 1, 1]
+    o[: n // 4, 1:] *= 0.05
+    k = rs.randint(0, T, n)
+    bary = rs.dirichlet([1, 1, 1], n)
+    tgt = np.einsum("nk,nkc->nc", bary, verts[k]) + rs.normal(0, 0.03, size=(n, 3))
+    d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    p1, t1 = ctx.intersect_rays(o, d, None, 1)
+    p0, t0 = ctx.intersect_rays(o, d, None, 0)
+    np.testing.assert_array_equal(p1, p0); np.testing.assert_array_equal(t1, t0)
+    assert (p0 >= 0).mean() > 0.4 and len(np.unique(p0[p0 >= 0])) == T          # every link of the chain is somebody's nearest hit
+    assert (p0[p0 >= 0] != k[p0 >= 0]).mean() > 0.3                             # ... and not always the one aimed at: an earlier link was in the way
+    nodes["offset"][0] = 1                          # ... while a malformed tree is still refused
+    with pytest.raises(Exception):
+        ctx.set_mesh(verts, none, none, nodes)
+
+
 def test_grid_march_equals_brute_force(ctx):
     """The march grid on meshes of very different grain -- 30 wall-sized triangles (config 4's scene: every triangle spans
     thousands of cells) and the 5140-triangle sphere -- at several resolutions: prim and t equal the brute-force scan's
     bit for bit on 30000 rays (same tri_hit, same nearest / tie rule; only the set of triangles tested differs)."""
     from light_transport_amd.src import bvh_new as B
     rs = np.random.RandomState(21)
+    seen = set()
     for (ordered, linear), half in ((S.cornell_scene(), 7.5), (S.sphere_in_box(3)[1:3], 4.0)):
         n = 30000
         o = rs.uniform(-half, half, size=(n, 3))
@@ -526,18 +593,22 @@ def test_grid_march_equals_brute_force(ctx):
         o[500:1500] = np.round(o[500:1500])                      # on cell walls of most resolutions
         tmax = np.where(rs.rand(n) < 0.3, np.inf, rs.exponential(0.5, size=n))
         p0, t0 = B.intersect_bvh_batch(o, d, ordered, linear, tmax, False, ctx)
-        for cells in ("16", "50", "128", ""):
-            if cells:
-                os.environ["LT_MARCH_CELLS"] = cells
-            else:
-                os.environ.pop("LT_MARCH_CELLS", None)
+        for cells in (16, 50, 128, -1):
+            ctx.set_tuning("march_cells", cells)
             ctx.set_mesh(B.triangles_array(ordered), -np.ones(len(ordered), np.int32), -np.ones(len(ordered), np.int32),
                          B.linear_bvh_arrays(linear))       # a fresh mesh: the grid is rebuilt at this resolution
             ctx._mesh_key = None
             for form in (2, 3):
                 p2, t2 = ctx.intersect_rays(o, d, tmax, form)
                 np.testing.assert_array_equal(p2, p0); np.testing.assert_array_equal(t2, t0)
+            info = ctx.mesh_accel_info()           # the knob really took: the grid has that many cells along its longest axis
+            assert info["kind"] & 2 and info["march_entries"] > 0
+            if cells > 0:
+                assert max(info["march_dims"]) == cells, info
+            else:
+                seen.add(max(info["march_dims"]))
         assert (p0 >= 0).mean() > 0.3
+    assert len(seen) == 2 and all(32 <= v <= 256 for v in seen)     # the default resolution follows the meshes' grain
 
 
 # ---------------------------------------------------------------- f3: meshes that came through the OBJ loader (G10)
@@ -792,32 +863,31 @@ def test_log_tally_equals_atomic_tally(ctx):
                     layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))
     big = S.Problem([(0.1, 10.0, 0.9, 1.0)], (300, 300, 200), (-15.0, -15.0, 0.0), (0.1,) * 3,
                     layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))   # 1300 tiles: two-pass partition
-    # (mode, log budget, lanes, LT_LOG_BITS2, LT_LOG_HOT): the two-pass form runs with the hot tiles the pilot batch
+    # (mode, log budget, lanes, knob log_bits2, knob log_hot): the two-pass form runs with the hot tiles the pilot batch
     # finds (default), with a handful of them, and without (plain two passes)
     regimes = (("atomic", 0, 1, None, None), ("log", 8 << 30, 1, None, None), ("log", 48 << 20, 1, None, None),
                ("log", 4 << 20, 1, None, None), ("log", 8 << 30, 2, None, None), ("log", 48 << 20, 2, None, "0"),
                ("log", 8 << 30, 3, None, "5"), ("log", 8 << 30, 1, "3", None), ("log", 48 << 20, 2, "2", None),
-               ("log", 8 << 30, 1, "3", "0"), ("log", 48 << 20, 3, "2", "3"))
+               ("log", 8 << 30, 1, "3", "0"), ("log", 48 << 20, 3, "2", "3"),
+               ("log", 4 << 20, 2, None, None))     # a budget that holds ONE lane's minimum log, not two: the launch must fall back to one lane
     for prob, n in ((S.slab(), 300000), (odd, 300000), (S.cornell(64), 100000), (big, 300000)):
         grids = {}
         c2 = lt.Context(0)        # ample logs first on the session ctx, small budgets later: both orders are covered
         for k, (mode, log_bytes, lanes, bits2, hot) in enumerate(regimes):
             cx = ctx if k % 2 == 0 else c2
-            if bits2 is not None:
-                os.environ["LT_LOG_BITS2"] = bits2
-            if hot is not None:
-                os.environ["LT_LOG_HOT"] = hot
-            try:
+            knobs = {k: int(v) for k, v in (("log_bits2", bits2), ("log_hot", hot)) if v is not None}
+            with cx.tuning(**knobs):
                 prob.apply(cx, "u64fx"); cx.set_tally_mode(mode, log_bytes); cx.set_overlap(lanes)
                 cx.launch(n, seed=5); cx.sync()
-            finally:
-                os.environ.pop("LT_LOG_BITS2", None); os.environ.pop("LT_LOG_HOT", None)
             grids[(mode, log_bytes, lanes, bits2, hot)] = (cx.read_grid_raw(), cx.read_counters())
             info = cx.last_log_info()
             if mode == "atomic":
                 assert info is None
                 continue
-            assert info["lanes"] == lanes and info["records"] + info["overflow_records"] > 50 * n
+            want_lanes = 1 if (log_bytes == 4 << 20 and lanes == 2) else lanes
+            assert info["lanes"] == want_lanes and info["records"] + info["overflow_records"] > 50 * n
+            if log_bytes == 4 << 20:
+                assert info["overflow_records"] > 0      # such a log overflows: every wave meets the exhausted state
             two_pass = bits2 is not None or prob is big
             n_hot = cx.last_log_hot_tiles()[0]
             if not two_pass or hot == "0":
@@ -870,13 +940,9 @@ def test_config5_geometry_512_cubed(ctx):
     n, off = 2 * 10 ** 6, 3 * 12500000
     grids = {}
     for mode, lanes, hot in (("atomic", 1, None), ("log", 1, None), ("log", 2, None), ("log", 1, "0"), ("log", 3, "100")):
-        if hot is not None:
-            os.environ["LT_LOG_HOT"] = hot
-        try:
+        with ctx.tuning(**({"log_hot": int(hot)} if hot is not None else {})):
             prob.apply(ctx, "u64fx"); ctx.set_tally_mode(mode); ctx.set_overlap(lanes)
             ctx.launch(n, seed=12, photon_offset=off); ctx.sync()
-        finally:
-            os.environ.pop("LT_LOG_HOT", None)
         grids[(mode, lanes, hot)] = (ctx.read_grid_raw(), ctx.read_counters())
         if mode == "log":
             info = ctx.last_log_info()
@@ -1023,30 +1089,37 @@ def test_random_layered_scenes_match_oracle(ctx):
 
 
 def test_surface_query_shortcuts_do_not_change_results(ctx):
-    """Mesh walks skip the BVH when the cell's clearance says no surface is within the hop, and test only the cell's
-    listed nearest triangles when nothing else is (WalkParams::clear records): both are shortcuts, not approximations.
-    u64 grids and step counts with the lists off (LT_NO_NEAR_LISTS=1), with the clearance grid off altogether
-    (LT_NO_CLEARANCE=1: every step queries the BVH), with a coarse / a fine grid, and with query services that wait for 1 or
-    for all 64 lanes are identical bit for bit, on the
-    Cornell cavity + cone (30 triangles in LDS, area source) and on the 5140-triangle sphere (tables in global memory)."""
-    cases = ((S.cornell(64), 200000), (S.sphere_in_box(4, split_method=0)[0], 60000))
-    variants = ({}, {"LT_NO_NEAR_LISTS": "1"}, {"LT_NO_CLEARANCE": "1"}, {"LT_CLEARANCE_CELLS": "16"}, {"LT_CLEARANCE_CELLS": "200"},
-                {"LT_QUERY_MIN": "1"}, {"LT_QUERY_MIN": "64"})      # ... nor does the number of lanes a query service waits for
-    for prob, n in cases:
+    """Every shortcut of the mesh walks is a shortcut, not an approximation: u64 grids and step counts are identical bit for
+    bit with each of them varied or switched off (lt_set_tuning).
+    Cornell cavity + cone (30 triangles in LDS, walk_kernel_q): near-triangle lists off; clearance grid off altogether (every
+    step queries the BVH); a coarse / a fine clearance grid; query services that wait for 1 or for all 64 lanes.
+    5140-triangle sphere (tables in global memory, walk_kernel_m): march grid of 16 / 200 cells; no march grid (walk_kernel_q
+    over the BVH, no clearance at all); candidate queue drained as soon as 1 / only when 64 answered queries wait."""
+    cornell_variants = ({}, {"no_near_lists": 1}, {"no_clearance": 1}, {"clearance_cells": 16}, {"clearance_cells": 200},
+                        {"query_min": 1}, {"query_min": 64})
+    sphere_variants = ({}, {"march_cells": 16}, {"march_cells": 200}, {"no_march": 1}, {"query_min": 1}, {"query_min": 64})
+    cornell_prob = S.cornell(64)
+    for prob, n, variants in ((cornell_prob, 200000, cornell_variants), (S.sphere_in_box(4, split_method=0)[0], 60000, sphere_variants)):
         ref = None
-        for env in variants:
-            os.environ.update(env)
-            try:
+        for knobs in variants:
+            with ctx.tuning(**knobs):
                 prob.apply(ctx, "u64fx"); ctx.set_tally_mode("atomic")
                 ctx.launch(n, seed=21); ctx.sync()
-            finally:
-                for k in env:
-                    os.environ.pop(k, None)
+                info = ctx.mesh_accel_info()
+            # the variant really ran: the acceleration data is what the knob asks for
+            if "march_cells" in knobs:
+                assert max(info["march_dims"]) == knobs["march_cells"], info
+            if "clearance_cells" in knobs:
+                assert max(info["clearance_dims"]) == knobs["clearance_cells"], info
+            if "no_march" in knobs or "no_clearance" in knobs:
+                assert info["kind"] == 0, info
+            if not knobs:
+                assert info["kind"] == (2 if prob is not cornell_prob else 1), info
             g, c = ctx.read_grid_raw(), ctx.read_counters()
             if ref is None:
                 ref = (g, c)
                 assert c["w_escaped_mesh"] > 0 and g.sum() > 0
-            assert c["steps"] == ref[1]["steps"] and np.array_equal(g, ref[0]), env
+            assert c["steps"] == ref[1]["steps"] and np.array_equal(g, ref[0]), knobs
     ctx.set_tally_mode(2)
 
 
