@@ -161,6 +161,7 @@ int lt_set_max_steps(lt_ctx* ctx, uint32_t max_steps);
  *   march_cells, march_scale_milli   march grid: cells along the longest axis / cell size in 1/1000 of the default
  *   clearance_cells    clearance grid of meshes in LDS: cells along the longest axis
  *   no_march, no_clearance, no_near_lists   switch the shortcut off (every query then takes the slower exact path)
+ *   force_march        meshes that fit LDS take the march grid and walk_kernel_m all the same (measurement)
  *   march_info         print the march grid's dimensions when it is built */
 int lt_set_tuning(lt_ctx* ctx, const char* key, int64_t value);
 /* LT_QUANTITY_*; applies to subsequent launches (the grid is NOT rescaled: zero it when switching) */

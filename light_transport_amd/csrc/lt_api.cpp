@@ -137,7 +137,7 @@ struct lt_ctx {
     struct Knobs {
         long query_min = -1, log_bits2 = -1, log_hot = -1, overlap_walk_bpc = -1, diag_no_tally = -1, log_timing = -1,
              march_cells = -1, march_scale_milli = -1, no_march = -1, no_clearance = -1, no_near_lists = -1,
-             clearance_cells = -1, march_info = -1;
+             clearance_cells = -1, march_info = -1, force_march = -1;
         std::string overlap_pattern;      // LT_OVERLAP_PATTERN (relative sub-batch sizes; tools/pattern_ab.py)
     } knob;
     long* knob_by_name(const char* key)
@@ -147,7 +147,7 @@ struct lt_ctx {
             {"overlap_walk_bpc", &Knobs::overlap_walk_bpc}, {"diag_no_tally", &Knobs::diag_no_tally}, {"log_timing", &Knobs::log_timing},
             {"march_cells", &Knobs::march_cells}, {"march_scale_milli", &Knobs::march_scale_milli}, {"no_march", &Knobs::no_march},
             {"no_clearance", &Knobs::no_clearance}, {"no_near_lists", &Knobs::no_near_lists}, {"clearance_cells", &Knobs::clearance_cells},
-            {"march_info", &Knobs::march_info}};
+            {"march_info", &Knobs::march_info}, {"force_march", &Knobs::force_march}};
         for (const auto& t : tab) if (std::strcmp(key, t.k) == 0) return &(knob.*(t.m));
         return nullptr;
     }
@@ -420,7 +420,7 @@ int upload_tables(lt_ctx* c)
         vq.f32 = 1;
         const bool lds32 = walk_lds_bytes(vq, nm, 0, ntr, nno) <= kMeshLdsBudget;
         c->have_march = false;
-        if (!lds64 && !c->on(c->knob.no_clearance) && !c->on(c->knob.no_march)) { if ((rc = build_march_grid(c))) return rc; }
+        if ((!lds64 || c->on(c->knob.force_march)) && !c->on(c->knob.no_clearance) && !c->on(c->knob.no_march)) { if ((rc = build_march_grid(c))) return rc; }
         // clearance grid over the root bounds: 64 cells along the longest axis (LT_NO_CLEARANCE=1 disables it)
         c->have_clear = false;
         // (only for meshes some walk variant stages in LDS: the f64-beyond-LDS kernels use the march grid or the plain BVH,
@@ -809,7 +809,7 @@ int lt_create(lt_ctx** out, int device_id)
     c->device = device_id;
     {   // the one place the environment is read: LT_QUERY_MIN, LT_LOG_HOT, ... seed the knobs of lt_set_tuning
         static const char* const names[] = {"query_min", "log_bits2", "log_hot", "overlap_walk_bpc", "diag_no_tally", "log_timing", "march_cells",
-                                            "march_scale_milli", "no_march", "no_clearance", "no_near_lists", "clearance_cells", "march_info"};
+                                            "march_scale_milli", "no_march", "no_clearance", "no_near_lists", "clearance_cells", "march_info", "force_march"};
         for (const char* k : names) {
             std::string name = "LT_";
             for (const char* q = k; *q; q++) name += (char)std::toupper((unsigned char)*q);
@@ -1096,7 +1096,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     LaunchCfg cfg;
     cfg.threads = c->threads_per_block > 0 ? c->threads_per_block : 256;
     cfg.lds_bytes = walk_lds_bytes(v, P.n_media, P.n_layers, P.n_tris, P.n_nodes);
-    if (v.mesh && cfg.lds_bytes > kMeshLdsBudget) {
+    if (v.mesh && (cfg.lds_bytes > kMeshLdsBudget || (c->on(c->knob.force_march) && c->have_march && !v.table))) {
         // large mesh: leave triangles and nodes in global memory (L2 / Infinity Cache resident)
         if (v.table) return c->fail(LT_E_UNSUPPORTED, "lt_launch: table RNG with a mesh beyond the LDS budget");
         v.mesh = c->have_march ? 3 : 2;      // with a march grid: walk_kernel_m

@@ -208,7 +208,7 @@ __device__ __forceinline__ uint32_t claimed_chunks(const LogReduceParams& L)
 // free then), so they fly during the write-out; the cursor atomics are issued before the digit scan and collected
 // after the LDS scatter.
 #ifndef LT_PART_WAVES
-#define LT_PART_WAVES 8
+#define LT_PART_WAVES 6
 #endif
 template <typename TV, int PASS, bool HOT>
 __global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogReduceParams L)

@@ -5,7 +5,13 @@ import light_transport_amd as lt
 from tests import scenes as S
 ctx = lt.Context(0)
 prob, n = S.cornell(256), 10 ** 7
-for mode, dtype, f32, lanes in (("atomic", "f64", False, 1), ("log", "f64", False, 1), ("log", "f64", False, 2), ("log", "f32", True, 1)):
+# C4_KNOBS="query_min=1,force_march=1": experiment knobs (lt_set_tuning) for every row
+for kv in filter(None, os.environ.get("C4_KNOBS", "").split(",")):
+    ctx.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
+rows = (("atomic", "f64", False, 1), ("log", "f64", False, 1), ("log", "f64", False, 2), ("log", "f32", True, 1))
+if os.environ.get("C4_ROWS"):
+    rows = tuple(r for k, r in enumerate(rows) if str(k) in os.environ["C4_ROWS"].split(","))
+for mode, dtype, f32, lanes in rows:
     prob.apply(ctx, dtype); ctx.set_tally_mode(mode); ctx.set_overlap(lanes)
     best = 1e9
     for r in range(3):
