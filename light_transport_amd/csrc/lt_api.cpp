@@ -730,6 +730,9 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         L.grid = bt.first >= 1 ? c->d_gridx[bt.first - 1].p : c->d_grid.p; L.n_vox = c->n_vox(); L.tally = c->tally;
         L.nx = (uint32_t)c->nx; L.ny = (uint32_t)c->ny; L.nz = (uint32_t)c->nz; L.ntx = G.ntx; L.nty = G.nty;
         L.flush_atomic = 0;
+        // one lane AND the caller has not asked for a walk at partial occupancy (lt_set_launch_config: what a host that keeps
+        // several contexts in flight does, bench.py's two_jobs / three_jobs): then nothing co-runs with this reduction
+        L.alone = (plan.lanes == 1 && c->blocks_per_cu == 0) ? 1 : 0;
         if (hot) { L.dmap = (const uint16_t*)c->d_dmap.p; L.dmeta = (const uint32_t*)c->d_dmeta.p; }
 
         HIP_TRY(c, hipMemsetAsync(ln.head.p, 0, sizeof(unsigned long long), s));

@@ -218,6 +218,8 @@ struct LogReduceParams {
     // Any map gives the same grid; a good one (k_log_plan, from a measured tile histogram) saves the second pass for
     // most records.  The walk's level-1 histogram is not used in this form: k_log_count1 counts the digits from the log.
     const uint16_t* dmap; const uint32_t* dmeta;
+    int alone;                                 // nothing shares the device with this lane's reduction (one lane, walk at full occupancy):
+                                               // the partition may take the register budget that leaves no room for a co-running walk
     int flush_atomic;                          // every tile adds to the grid with atomics (another lane of the same
                                                // launch may be updating it at the same time)
 };

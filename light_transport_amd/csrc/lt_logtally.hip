@@ -207,11 +207,19 @@ __device__ __forceinline__ uint32_t claimed_chunks(const LogReduceParams& L)
 // Software pipeline: the next item's loads are issued as soon as this item's records sit in LDS (their registers are
 // free then), so they fly during the write-out; the cursor atomics are issued before the digit scan and collected
 // after the LDS scatter.
-#ifndef LT_PART_WAVES
-#define LT_PART_WAVES 6
+// Two register budgets.  CORUN (64 VGPRs, the f64 build spills 28 B per lane): two partition workgroups fit a CU beside a
+// walk that runs at two workgroups per CU -- the overlapped regimes (lanes inside a launch, jobs in flight).  ALONE (80
+// VGPRs, no scratch): nothing shares the CU; C2's partition 10.59 -> 9.38 ms.  Measured both ways (profiles/r03a_*.log):
+// the ALONE build beside a walk costs C5's two-pass partition its second workgroup per CU -- two_jobs 61.3-63.1 -> 65.7 ms,
+// one call 60.4-60.7 -> 64.5 ms per share -- so it is used only where LogReduceParams::alone says nothing co-runs.
+#ifndef LT_PART_WAVES_CORUN
+#define LT_PART_WAVES_CORUN 8
 #endif
-template <typename TV, int PASS, bool HOT>
-__global__ void __launch_bounds__(kPartThreads, LT_PART_WAVES) k_log_part(LogReduceParams L)
+#ifndef LT_PART_WAVES_ALONE
+#define LT_PART_WAVES_ALONE 6
+#endif
+template <typename TV, int PASS, bool HOT, bool ALONE>
+__global__ void __launch_bounds__(kPartThreads, ALONE ? LT_PART_WAVES_ALONE : LT_PART_WAVES_CORUN) k_log_part(LogReduceParams L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     TV* s_val = reinterpret_cast<TV*>(s_dyn);                                                   // [kPartItem]
@@ -624,18 +632,22 @@ static unsigned persistent_blocks(BlockCache& cache, const void* fn, int threads
 // (and the cached persistent grid) does not depend on the scene
 constexpr size_t kMapLds = (size_t)kMaxHotTiles * sizeof(uint16_t) + 4;
 
-template <typename TV, int PASS, bool HOT> static hipError_t launch_part_t(const LogReduceParams& L, hipStream_t s)
+template <typename TV, int PASS, bool HOT, bool ALONE> static hipError_t launch_part_ta(const LogReduceParams& L, hipStream_t s)
 {
     const size_t lds = (size_t)kPartItem * (sizeof(TV) + sizeof(uint32_t)) + (size_t)(2 * kMaxBins + 2) * sizeof(uint32_t) +
                        (HOT ? kMapLds : 0);
-    const void* fn = reinterpret_cast<const void*>(&k_log_part<TV, PASS, HOT>);
+    const void* fn = reinterpret_cast<const void*>(&k_log_part<TV, PASS, HOT, ALONE>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     static BlockCache blocks{};   // per instantiation
-    hipLaunchKernelGGL((k_log_part<TV, PASS, HOT>), dim3(persistent_blocks(blocks, fn, kPartThreads, lds)), dim3(kPartThreads), lds, s, L);
+    hipLaunchKernelGGL((k_log_part<TV, PASS, HOT, ALONE>), dim3(persistent_blocks(blocks, fn, kPartThreads, lds)), dim3(kPartThreads), lds, s, L);
     return hipGetLastError();
+}
+template <typename TV, int PASS, bool HOT> static hipError_t launch_part_t(const LogReduceParams& L, hipStream_t s)
+{
+    return L.alone ? launch_part_ta<TV, PASS, HOT, true>(L, s) : launch_part_ta<TV, PASS, HOT, false>(L, s);
 }
 template <int PASS, bool HOT> static hipError_t launch_part(const LogReduceParams& L, hipStream_t s)
 {
