@@ -157,6 +157,9 @@ int lt_set_max_steps(lt_ctx* ctx, uint32_t max_steps);
  *   log_bits2, log_hot two-pass partition: width of the second digit; cap on the number of hot tiles (0: plain two-pass)
  *   overlap_walk_bpc   workgroups per CU of a walk that shares the device with another lane's reduction     (1..8)
  *   diag_no_tally      time the walk without deposition;   log_timing  print per-stage device times of every launch
+ *   tail_split         slab walks in log mode: 0 = the whole walk in one kernel; default = split (a wave hands its last
+ *                      photons to the tail kernel when at most 32 lanes are alive) where a drain is exposed and the batch
+ *                      has >= 512 photons per launched wave; n >= 2 = split with threshold n (<= 48) whatever the size
  *   -- taking effect when the mesh tables are next built (lt_set_mesh + launch / query):
  *   march_cells, march_scale_milli   march grid: cells along the longest axis / cell size in 1/1000 of the default
  *   clearance_cells    clearance grid of meshes in LDS: cells along the longest axis

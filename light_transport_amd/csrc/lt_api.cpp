@@ -58,11 +58,14 @@ constexpr int kAutoLanes = 2;     // auto mode tries 1 and 2: a third lane measu
 
 struct LogLane {
     hipStream_t stream = nullptr;
+    // tail split: the stream the tail kernel of a batch runs on (beside the lane's log reduction), its pool and events
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t ev_bulk = nullptr, ev_tail = nullptr;
     hipEvent_t ev_done = nullptr;          // end of the lane's last batch
     std::vector<hipEvent_t> evs;           // 5 per batch of the last launch: walk start / end, scan end, partition end, reduce end
     size_t ev_used = 0;
     DevBuf log_idx, log_val, tmp_idx, tmp_val, log_fill, meta, hist1, hist_unused, hist, bin_base, bin_cnt, tile_base, tile_cnt, cursor1,
-        cursor2, items2, items_c, items_r, itab, head;
+        cursor2, items2, items_c, items_r, itab, head, pool, pool_n;
     size_t alloc_records = 0;              // capacity of the log buffers currently allocated (without the slack)
     int alloc_elem = 0;
     void release_log() { log_idx.release(); log_val.release(); tmp_idx.release(); tmp_val.release(); log_fill.release(); alloc_records = 0; }
@@ -70,7 +73,7 @@ struct LogLane {
     {
         release_log(); meta.release(); hist1.release(); hist_unused.release(); hist.release(); bin_base.release(); bin_cnt.release(); tile_base.release();
         tile_cnt.release(); cursor1.release(); itab.release();
-        cursor2.release(); items2.release(); items_c.release(); items_r.release(); head.release();
+        cursor2.release(); items2.release(); items_c.release(); items_r.release(); head.release(); pool.release(); pool_n.release();
     }
 };
 
@@ -137,7 +140,7 @@ struct lt_ctx {
     struct Knobs {
         long query_min = -1, log_bits2 = -1, log_hot = -1, overlap_walk_bpc = -1, diag_no_tally = -1, log_timing = -1,
              march_cells = -1, march_scale_milli = -1, no_march = -1, no_clearance = -1, no_near_lists = -1,
-             clearance_cells = -1, march_info = -1, force_march = -1;
+             clearance_cells = -1, march_info = -1, force_march = -1, tail_split = -1;
         std::string overlap_pattern;      // LT_OVERLAP_PATTERN (relative sub-batch sizes; tools/pattern_ab.py)
     } knob;
     long* knob_by_name(const char* key)
@@ -147,7 +150,7 @@ struct lt_ctx {
             {"overlap_walk_bpc", &Knobs::overlap_walk_bpc}, {"diag_no_tally", &Knobs::diag_no_tally}, {"log_timing", &Knobs::log_timing},
             {"march_cells", &Knobs::march_cells}, {"march_scale_milli", &Knobs::march_scale_milli}, {"no_march", &Knobs::no_march},
             {"no_clearance", &Knobs::no_clearance}, {"no_near_lists", &Knobs::no_near_lists}, {"clearance_cells", &Knobs::clearance_cells},
-            {"march_info", &Knobs::march_info}, {"force_march", &Knobs::force_march}};
+            {"march_info", &Knobs::march_info}, {"force_march", &Knobs::force_march}, {"tail_split", &Knobs::tail_split}};
         for (const auto& t : tab) if (std::strcmp(key, t.k) == 0) return &(knob.*(t.m));
         return nullptr;
     }
@@ -480,6 +483,7 @@ int collect_log_stats(lt_ctx* c)
 constexpr uint32_t kMaxLogTiles = 65536;              // tiled record index = tile << 14 | position: 30 bits
 constexpr uint64_t kPilotPhotons = 16384;             // pilot batch that measures a new scene's record rate
 constexpr uint64_t kOverlapMinPhotons = 1ull << 21;   // overlap auto: launches below this stay on one lane
+constexpr uint64_t kTailSplitMinPerWave = 512;        // tail split: photons per launched wave below which a batch walks in one kernel
 
 struct LogGeom { uint32_t ntx, nty, ntz, n_tiles, bits2, nb1; };
 
@@ -740,9 +744,50 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         HIP_TRY(c, hipMemsetAsync(ln.hist.p, 0, (size_t)G.n_tiles * (G.bits2 ? kLogGroups2 : kLogGroups) * 4, s));
         HIP_TRY(c, hipMemsetAsync(ln.log_fill.p, 0, (size_t)P.log_cap_chunks * 4, s));   // unclaimed chunk indices read as empty
         if (G.bits2) HIP_TRY(c, hipMemsetAsync(ln.hist1.p, 0, (size_t)(hot ? log_max_digits() : G.nb1) * kLogGroups * 4, s));
+        // Tail split (slab walks, XORWOW, batches large enough to have a drain worth hiding): the walk kernel hands the
+        // last photons of every wave to a pool and ends; the tail kernel finishes them on the lane's tail stream, with
+        // atomic deposits, WHILE the log reduction of this batch runs here.  The reduction then flushes with atomics too.
+        // Only where a drain is exposed: the LAST batch of the launch (earlier batches drain beside the next batch's walk),
+        // or every batch of a one-lane launch (there the partition waits for each drain).
+        // ... and only where the drain is a small part of the batch: the tail's deposits are per-deposit atomics, the slow
+        // path the log exists to avoid.  A batch of fewer than kTailSplitMinPerWave photons per launched wave is "all tail"
+        // (300 000 photons over 4096 waves: 73 each -- measured: 84 % of the records took the atomic route).
+        // lt_set_tuning("tail_split", n >= 2) forces the split with threshold n whatever the size (tests).
+        const bool last_batch = &bt == &plan.batches.back();
+        const uint64_t waves_launched = (uint64_t)cfg.blocks * (uint64_t)(cfg.threads / 64);
+        const bool big_enough = c->knob.tail_split >= 2 || bt.second >= kTailSplitMinPerWave * waves_launched;
+        const bool split = R.v.mesh == 0 && !R.v.table && !R.v.capture && c->knob.tail_split != 0 && big_enough &&
+                           ((plan.lanes == 1 && c->blocks_per_cu == 0) || (plan.lanes > 1 && last_batch));      // (a host that runs walks at
+                           // partial occupancy keeps several contexts in flight: their drains are hidden already, a tail kernel only adds contention)
+        Variant vw = R.v;
+        if (split) {
+            const size_t cap = (size_t)cfg.blocks * (size_t)(cfg.threads / 64) * kDumpPoolLanes;      // every wave hands over at most that many
+            P.dump_max = c->knob.tail_split > 1 ? (uint32_t)std::min<long>(c->knob.tail_split, (long)kDumpPoolLanes) : kDumpMaxLanes;
+            HIP_TRY(c, ln.pool.ensure(cap * (R.v.f32 ? sizeof(SurvD<float>) : sizeof(SurvD<double>))));
+            HIP_TRY(c, ln.pool_n.ensure(4));
+            if (!ln.tail_stream) HIP_TRY(c, hipStreamCreateWithFlags(&ln.tail_stream, hipStreamNonBlocking));
+            if (!ln.ev_bulk) HIP_TRY(c, hipEventCreateWithFlags(&ln.ev_bulk, hipEventDisableTiming));
+            if (!ln.ev_tail) HIP_TRY(c, hipEventCreateWithFlags(&ln.ev_tail, hipEventDisableTiming));
+            HIP_TRY(c, hipMemsetAsync(ln.pool_n.p, 0, 4, s));
+            P.pool = ln.pool.p; P.pool_n = (uint32_t*)ln.pool_n.p; P.pool_cap = (uint32_t)cap;
+            vw.phase = 1;
+        }
         HIP_TRY(c, lane_event(ln, s));
-        HIP_TRY(c, launch_walk(P, R.v, cfg, s));
+        HIP_TRY(c, launch_walk(P, vw, cfg, s));
         HIP_TRY(c, lane_event(ln, s));
+        if (split) {
+            HIP_TRY(c, hipEventRecord(ln.ev_bulk, s));
+            HIP_TRY(c, hipStreamWaitEvent(ln.tail_stream, ln.ev_bulk, 0));
+            WalkParams Pt = P;
+            Pt.log_idx = nullptr; Pt.log_val = nullptr; Pt.log_n_hist = 0;       // the tail deposits with atomics into the lane's grid
+            Variant vt = R.v; vt.phase = 2;
+            LaunchCfg ct = cfg;
+            ct.lds_bytes = walk_lds_bytes(vt, P.n_media, P.n_layers, P.n_tris, P.n_nodes, 0);
+            ct.blocks = (int)((P.pool_cap / 64u + (unsigned)(cfg.threads / 64) - 1) / (unsigned)(cfg.threads / 64));     // 64 pool entries per wave
+            if (ct.blocks < 1) ct.blocks = 1;
+            HIP_TRY(c, launch_walk(Pt, vt, ct, ln.tail_stream));
+            HIP_TRY(c, hipEventRecord(ln.ev_tail, ln.tail_stream));
+        }
         if (hot) HIP_TRY(c, launch_log_count1(L, s));
         HIP_TRY(c, G.bits2 ? launch_log_scan_bins(L, s) : launch_log_scan_tiles(L, s));
         HIP_TRY(c, lane_event(ln, s));
@@ -751,8 +796,10 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         if (G.bits2 == 0) { Lr.log_idx = L.tmp_idx; Lr.log_val = L.tmp_val; }   // one pass: tiles are final in tmp
         else HIP_TRY(c, launch_log_part2(L, s));                                  // tile counts, their scan, pass 2
         HIP_TRY(c, lane_event(ln, s));
+        if (split) Lr.flush_atomic = 1;        // the tail kernel may be adding to the same voxels
         HIP_TRY(c, launch_log_reduce(Lr, s));
         HIP_TRY(c, lane_event(ln, s));
+        if (split) HIP_TRY(c, hipStreamWaitEvent(s, ln.ev_tail, 0));      // the batch is complete when its tail is (and the pool may be reused)
         if (bt.first == 0 && G.bits2) c->tile_cnt_ready = true;      // lane 0's tile_cnt: this scene's records per tile
         offset += bt.second;
         (*n_batches)++;
@@ -812,7 +859,7 @@ int lt_create(lt_ctx** out, int device_id)
     c->device = device_id;
     {   // the one place the environment is read: LT_QUERY_MIN, LT_LOG_HOT, ... seed the knobs of lt_set_tuning
         static const char* const names[] = {"query_min", "log_bits2", "log_hot", "overlap_walk_bpc", "diag_no_tally", "log_timing", "march_cells",
-                                            "march_scale_milli", "no_march", "no_clearance", "no_near_lists", "clearance_cells", "march_info", "force_march"};
+                                            "march_scale_milli", "no_march", "no_clearance", "no_near_lists", "clearance_cells", "march_info", "force_march", "tail_split"};
         for (const char* k : names) {
             std::string name = "LT_";
             for (const char* q = k; *q; q++) name += (char)std::toupper((unsigned char)*q);
@@ -872,6 +919,11 @@ int lt_destroy(lt_ctx* c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int k = 0; k < kMaxLanes; k++) {
+        if (c->lanes[k].tail_stream) { (void)hipStreamSynchronize(c->lanes[k].tail_stream); (void)hipStreamDestroy(c->lanes[k].tail_stream); }
+        if (c->lanes[k].ev_bulk) (void)hipEventDestroy(c->lanes[k].ev_bulk);
+        if (c->lanes[k].ev_tail) (void)hipEventDestroy(c->lanes[k].ev_tail);
+    }
     for (int k = 1; k < kMaxLanes; k++) if (c->lanes[k].stream) (void)hipStreamDestroy(c->lanes[k].stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1040,6 +1092,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     v.table = rng_table ? 1 : 0;
     v.tally = c->tally;
     v.capture = c->max_vertices > 0 ? 1 : 0;
+    v.phase = 0;
     if (v.capture && (v.f32 || v.table)) return c->fail(LT_E_UNSUPPORTED, "lt_launch: vertex capture runs the f64 walk with the XORWOW generator");
     if (c->on(c->knob.diag_no_tally)) v.tally = 3;  // diagnostic: time the walk without deposition
     if (v.table && v.f32) return c->fail(LT_E_UNSUPPORTED, "lt_launch: table RNG runs the f64 walk only");

@@ -78,6 +78,20 @@ struct MarchGrid {
     double nudge64, nudge32;       // by how much the f64 / f32 march steps past a cell wall (<< the margin of the lists)
 };
 
+// A photon in flight, as walk_kernel<..., PHASE 1> hands it over and walk_kernel<..., PHASE 2> takes it up (see "tail split"
+// in lt_walk_kernel.inc): everything the walk keeps per lane -- position, direction, weight, unused optical depth, layer,
+// step count, id, and the XORWOW state (rocrand_state_xorwow without the Box-Muller cache: d + x[5]).
+template <typename R>
+struct SurvD {
+    R p[3], u[3], w, sleft;
+    unsigned long long pid;
+    int32_t cur;
+    uint32_t step;
+    uint32_t rng[6];
+};
+constexpr uint32_t kDumpMaxLanes = 32;     // a wave hands its photons over when the queue is empty and at most this many are alive (default)
+constexpr uint32_t kDumpPoolLanes = 48;    // what the pool is sized for per wave (the knob tail_split = n sets the threshold, at most this)
+
 struct WalkParams {
     // photon queue
     unsigned long long* head;
@@ -125,6 +139,11 @@ struct WalkParams {
     int cnx, cny, cnz;
     double corg[3], cinv[3];
     MarchGrid mg;         // GEOM 2 (cell == null: off -> every hop walks the BVH)
+    // tail split (slab walks in log mode): pool of photons handed from the bulk kernel to the tail kernel
+    void* pool;           // SurvD<R>[pool_cap]
+    uint32_t* pool_n;     // entries claimed (may exceed pool_cap: the excess was not written and those photons walked on)
+    uint32_t pool_cap;
+    uint32_t dump_max;    // PHASE 1: hand over when at most this many lanes of the wave are alive
     // light sub-path capture (null = off)
     lt_vertex* vertices;
     uint32_t* vertex_counts;
@@ -143,6 +162,7 @@ struct Variant {
     int table;   // 0: XORWOW, 1: table RNG
     int tally;   // LT_TALLY_*
     int capture; // 1: the build that stores light sub-path vertices (f64 walk, XORWOW)
+    int phase;   // slab walks: 0 whole walk, 1 bulk (hands the last photons of every wave to a pool), 2 tail (walks the pool)
 };
 
 hipError_t launch_walk(const WalkParams& P, const Variant& v, const LaunchCfg& cfg, hipStream_t s);

@@ -1021,8 +1021,25 @@ static WalkFn pick_geom(const Variant& v)
     if constexpr (!TABLE) return pick_tally<R, 2, TABLE, CAPTURE>(v.tally); else return nullptr;
 }
 
+// slab walks in two kernels (Variant::phase 1 / 2, lt_walk_kernel.inc "Tail split"): XORWOW, no capture
+template <typename R, int PHASE>
+static WalkFn pick_phase(int tally)
+{
+    switch (tally) {
+    case LT_TALLY_F32: return walk_kernel<R, 0, false, LT_TALLY_F32, false, PHASE>;
+    case LT_TALLY_F64: return walk_kernel<R, 0, false, LT_TALLY_F64, false, PHASE>;
+    case LT_TALLY_U64FX: return walk_kernel<R, 0, false, LT_TALLY_U64FX, false, PHASE>;
+    }
+    return nullptr;
+}
+
 static WalkFn pick(const Variant& v)
 {
+    if (v.phase) {
+        if (v.mesh || v.table || v.capture) return nullptr;
+        if (v.phase == 1) return v.f32 ? pick_phase<float, 1>(v.tally) : pick_phase<double, 1>(v.tally);
+        return v.f32 ? pick_phase<float, 2>(v.tally) : pick_phase<double, 2>(v.tally);
+    }
     if (v.capture) return (v.f32 || v.table) ? nullptr : pick_geom<double, false, true>(v);
     if (v.f32) return v.table ? nullptr : pick_geom<float, false, false>(v);
     return v.table ? pick_geom<double, true, false>(v) : pick_geom<double, false, false>(v);

@@ -965,6 +965,32 @@ def test_config5_geometry_512_cubed(ctx):
     ctx.set_grid((8, 8, 8), (0, 0, 0), (1, 1, 1), "f64")     # release the 1 GiB grid of the session ctx
 
 
+def test_tail_split_changes_nothing_but_the_route(ctx):
+    """Slab walks in log mode end their walk kernel early and finish the last photons of every wave in a second kernel beside
+    the log reduction (lt_walk_kernel.inc "Tail split").  Off (knob 0), default, and forced with thresholds 16 / 48 (a wave hands over when at
+    most that many lanes are alive): identical u64 grids and step counts on the slab and the two-layer scene, one and two lanes -- and the
+    number of deposit records that went through the LOG differs, which proves photons really took the other route (their
+    deposits reach the grid as atomics from the tail kernel)."""
+    for prob in (S.slab(), S.two_layer()):
+        for lanes in (1, 2):
+            seen = {}
+            for knob in (0, -1, 16, 48):       # off / default / forced with thresholds 16 and 48
+                with ctx.tuning(tail_split=knob):
+                    prob.apply(ctx, "u64fx"); ctx.set_tally_mode("log"); ctx.set_overlap(lanes)
+                    ctx.launch(600000, seed=31); ctx.sync()
+                g, c, info = ctx.read_grid_raw(), ctx.read_counters(), ctx.last_log_info()
+                seen[knob] = (g, c["steps"], info["records"] + info["overflow_records"])
+            for knob in (-1, 16, 48):
+                assert seen[knob][1] == seen[0][1] and np.array_equal(seen[knob][0], seen[0][0]), (lanes, knob)
+            assert seen[48][2] < seen[16][2] < seen[0][2], (lanes, [v[2] for v in seen.values()])
+            # the DEFAULT does not split a launch this small (146 photons per wave: it would be "all tail", atomics for most
+            # deposits): every record goes through the log, as with the split off
+            # (record counts of two identical launches differ by a few: which photons share a lane -- and so which consecutive
+            #  same-voxel deposits the run-length accumulator merges -- depends on scheduling; a split moves millions)
+            assert abs(seen[-1][2] - seen[0][2]) <= 1e-5 * seen[0][2] and seen[16][2] < 0.99 * seen[0][2], (lanes, [v[2] for v in seen.values()])
+    ctx.set_tally_mode("auto"); ctx.set_overlap(0)
+
+
 def test_overlap_auto_tries_both_regimes_then_keeps_one(ctx):
     """lt_set_overlap(0): launches of >= 2^21 photons whose geometry is not pinned run once with two lanes, once with
     one, then with whichever took less device time per photon; results do not depend on it (bit-identical u64 grids)."""
