@@ -404,12 +404,25 @@ def main(argv=None):
     if rank == 0 and not args.no_alone:
         c = ctxs[0]
         c.set_overlap(1); c.set_launch_config(0, 0)
+        # the shipping default first (with the tail split where it applies: the walk's last photons finish in a second kernel
+        # BESIDE the log reduction) = what one synchronous caller on one lane gets ...
+        ms_default = []
+        if hasattr(c, "set_tuning"):
+            for k in range(3):
+                c.zero_tally(); c.launch(per_gpu, seed=510 + k, photon_offset=offset, f32_walk=args.f32_walk); c.sync()
+                ms_default.append(c.last_kernel_ms()); note(c)
+            c.set_tuning("tail_split", 0)
+        # ... then with the split off, so that every kernel really runs alone: these durations feed the per-kernel rooflines
         ms, st = [], None
         for k in range(3):
             c.zero_tally(); c.launch(per_gpu, seed=500 + k, photon_offset=offset, f32_walk=args.f32_walk); c.sync()
             ms.append(c.last_kernel_ms())
             st = note(c)
+        if hasattr(c, "set_tuning"):
+            c.set_tuning("tail_split", -1)
         alone = {"job_ms": float(np.mean(ms[1:]))}
+        if ms_default:
+            alone["job_ms_shipping_default"] = float(np.mean(ms_default[1:]))
         if st is not None:
             alone.update({k: st[k] for k in ("walk_ms", "scan_ms", "partition_ms", "reduce_ms")})
             alone["batches"] = st["batches"]
@@ -516,7 +529,8 @@ def main(argv=None):
                             "one partition dispatch per batch")}
         if alone:
             alone["note"] = ("one job alone on the device, one lane (default launch geometry, 4 waves/SIMD), 2 launches after the "
-                             "timed region: single-job latency and kernel durations nothing overlaps")
+                             "timed region, tail split OFF: kernel durations nothing overlaps (the per-kernel rooflines); "
+                             "job_ms_shipping_default = the same job as a caller gets it (tail split on where it applies)")
             out["roofline"]["one_job_alone"] = alone
         if readback_ms is not None:
             gb = wl["grid"] ** 3 * REC_VALUE_BYTES[args.tally] / 1e9

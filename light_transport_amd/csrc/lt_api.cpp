@@ -757,7 +757,9 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         const uint64_t waves_launched = (uint64_t)cfg.blocks * (uint64_t)(cfg.threads / 64);
         const bool big_enough = c->knob.tail_split >= 2 || bt.second >= kTailSplitMinPerWave * waves_launched;
         const bool split = R.v.mesh == 0 && !R.v.table && !R.v.capture && c->knob.tail_split != 0 && big_enough &&
-                           ((plan.lanes == 1 && c->blocks_per_cu == 0) || (plan.lanes > 1 && last_batch));      // (a host that runs walks at
+                           ((plan.lanes == 1 && c->blocks_per_cu == 0 && (!R.v.f32 || c->knob.tail_split >= 2)) || (plan.lanes > 1 && last_batch));
+                           // (one lane, f32 walk: measured a LOSS -- 28.9 -> 31.6 ms on C2: the partition beside the tail kernel takes
+                           //  3 ms longer and the f32 drain is short -- so it is left out there.)  (A host that runs walks at
                            // partial occupancy keeps several contexts in flight: their drains are hidden already, a tail kernel only adds contention)
         Variant vw = R.v;
         if (split) {

@@ -33,6 +33,7 @@ class FakeContext:
     def set_overlap(self, lanes): self.lanes = lanes; self._log("set_overlap", lanes=lanes)
     def set_launch_config(self, b, t): self._log("set_launch_config", bpc=b, threads=t)
     def reserve_log(self, n): self._log("reserve_log", n=n)
+    def set_tuning(self, key, value=-1): self._log("set_tuning", key=key, value=value)
 
     # run
     def zero_tally(self):

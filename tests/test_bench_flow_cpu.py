@@ -46,10 +46,10 @@ def test_bench_control_flow_world_size_2(tmp_path, regime, flags):
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 * K - expect_steps) < 1e-6 * expect_steps
     for rk, cl in enumerate(calls):
         # both ranks issue the same sequence of operations per context (collectives in the same order)
-        def sig(x):      # (rank 0 alone runs three more jobs, seeds 500.., after the timed region)
-            return [(c["ctx"], c["op"]) for c in x if c["op"] == "reduce" or (c["op"] == "launch" and not 500 <= c["seed"] < 503)]
+        def sig(x):      # (rank 0 alone runs six more jobs after the timed region: seeds 510.. shipping default, 500.. tail split off)
+            return [(c["ctx"], c["op"]) for c in x if c["op"] == "reduce" or (c["op"] == "launch" and not 500 <= c["seed"] < 513)]
         assert sig(cl) == sig(calls[0])
-        launches = [c for c in cl if c["op"] == "launch" and not 500 <= c["seed"] < 503]
+        launches = [c for c in cl if c["op"] == "launch" and not 500 <= c["seed"] < 513]
         assert all(c["offset"] == rk * n and c["n"] == n for c in launches)          # disjoint photon-id ranges
         timed = [c for c in launches if c["seed"] < K]
         assert sorted(c["seed"] for c in timed) == list(timed_seeds)                   # EXACTLY K timed steps
@@ -71,6 +71,9 @@ def test_bench_control_flow_world_size_2(tmp_path, regime, flags):
     assert out["config"]["jobs_in_flight"] == depth
     timed_ctx = {c["ctx"] for c in calls[0] if c["op"] == "launch" and c["seed"] < K}
     assert len(timed_ctx) == depth
+    # rank 0's reference jobs: the split is switched off for the unoverlapped kernel times and restored afterwards
+    tun = [(c["key"], c["value"]) for c in calls[0] if c["op"] == "set_tuning"]
+    assert tun == [("tail_split", 0), ("tail_split", -1)] and not any(c["op"] == "set_tuning" for c in calls[1])
     # only rank 0 reads the grid back, after the timed region
     assert any(c["op"] == "read_grid_into" for c in calls[0]) and not any(c["op"] == "read_grid_into" for c in calls[1])
 
