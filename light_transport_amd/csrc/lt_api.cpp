@@ -321,7 +321,12 @@ int build_march_grid(lt_ctx* c)
     int n[3];
     for (int k = 0; k < 3; k++) {
         n[k] = (int)std::ceil(ext[k] / h); if (n[k] < 1) n[k] = 1;
-        G.h[k] = ext[k] > 0 ? ext[k] / n[k] : h; G.org[k] = c->nodes[0].lo[k]; G.inv[k] = 1.0 / G.h[k];
+        G.h[k] = ext[k] > 0 ? ext[k] / n[k] : h;
+        // one cell of margin on every side: photons just outside the root bounds -- around an OPEN mesh, next to a flat one
+        // (zero extent on an axis: the sheet would otherwise lie ON the grid's wall and half of space outside it) -- are
+        // still inside the grid and marched; only origins farther out take the BVH
+        n[k] += 2;
+        G.org[k] = c->nodes[0].lo[k] - G.h[k]; G.inv[k] = 1.0 / G.h[k];
     }
     G.nx = n[0]; G.ny = n[1]; G.nz = n[2];
     const size_t cells = (size_t)n[0] * n[1] * n[2];

@@ -129,6 +129,40 @@ def sphere_in_box(subdiv=4, n=48, split_method=0, **kw):
     return Problem(media, (n, n, n), (-dim, -dim, -dim), (voxel,) * 3, mesh=mesh, source=src, **kw), ordered, linear
 
 
+def open_sheets(n=24, **kw):
+    """An OPEN mesh beyond the LDS budget: a bumpy 40 x 40 sheet (3200 triangles) over an exactly flat 30 x 30 one (1800), no box
+    around them -- photons roam all around the mesh, outside its bounding box too, and the flat sheet has zero extent on z.
+    Medium 1 between the sheets, exterior below the flat one; a handful of zero-area triangles are mixed in."""
+    from light_transport_amd.src.io import triangles_from_mesh
+
+    def sheet(m, half, zf):
+        xs = np.linspace(-half, half, m + 1)
+        X, Y = np.meshgrid(xs, xs, indexing="ij")
+        V = np.stack([X, Y, zf(X, Y)], axis=-1).reshape(-1, 3)
+        idx = lambda i, j: i * (m + 1) + j      # noqa: E731
+        F = []
+        for i in range(m):
+            for j in range(m):      # counter-clockwise seen from +z: normals point up
+                F += [(idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)), (idx(i, j), idx(i + 1, j + 1), idx(i, j + 1))]
+        return V, np.array(F)
+    v1, f1 = sheet(40, 4.0, lambda X, Y: 0.3 * np.sin(1.3 * X) * np.cos(0.9 * Y))
+    v2, f2 = sheet(30, 3.0, lambda X, Y: np.full_like(X, -2.0))
+    bumpy = triangles_from_mesh(v1, f1, K.GLASS_MAT, drop_degenerate=False)
+    flat = triangles_from_mesh(v2, f2, K.GLASS_MAT, drop_degenerate=False)
+    deg = triangles_from_mesh(np.array([[0.5, 0.5, 1.0], [1.5, 1.5, 1.0], [1.0, 1.0, 1.0], [2.0, 0.0, -1.0]]),
+                              np.array([(0, 1, 2), (3, 3, 3), (0, 0, 1)]), K.GLASS_MAT, drop_degenerate=False)      # collinear / coincident vertices
+    for t in bumpy + deg:
+        t.med_front, t.med_back = 0, 1
+    for t in flat:
+        t.med_front, t.med_back = 1, -1
+    ordered, linear = B.build_linear_bvh(bumpy + flat + deg, 0)
+    mesh = dict(verts=B.triangles_array(ordered), med_front=np.array([t.med_front for t in ordered], np.int32),
+                med_back=np.array([t.med_back for t in ordered], np.int32), nodes=B.linear_bvh_arrays(linear))
+    media = [(0.05, 5.0, 0.8, 1.0), (0.8, 8.0, 0.9, 1.37)]
+    src = dict(type=0, pos=(0.1, -0.2, 3.0), dir=(0.05, 0.02, -1.0), extra=(0.0,) * 6, start_medium=0)
+    return Problem(media, (n, n, n), (-6.0, -6.0, -6.0), (12.0 / n,) * 3, mesh=mesh, source=src, **kw), ordered, linear
+
+
 def g8_inputs(g8, name):
     """Build the mesh (my BVH builder over the fixture's triangles) and tables of a G8 render."""
     from light_transport_amd.src.io import triangles_from_mesh
