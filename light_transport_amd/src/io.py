@@ -37,14 +37,11 @@ def read_obj(path):
 
 def triangles_from_mesh(vertices, faces, material, scale=1.0, translate=(0.0, 0.0, 0.0), drop_degenerate=True):
     v = np.asarray(vertices, dtype=np.float64) * float(scale) + np.asarray(translate, dtype=np.float64)
-    out = []
-    for a, b, c in np.asarray(faces, dtype=np.int64):
-        if drop_degenerate:
-            n = np.cross(v[b] - v[a], v[c] - v[a])
-            if not np.dot(n, n) > 0.0:
-                continue
-        out.append(PreComputedTriangle(v[a], v[b], v[c], material))
-    return out
+    f = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    if drop_degenerate and len(f):
+        n = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+        f = f[np.array([np.dot(r, r) > 0.0 for r in n])]
+    return PreComputedTriangle.batch(v[f[:, 0]], v[f[:, 1]], v[f[:, 2]], material) if len(f) else []
 
 
 def load_obj(file_path, material=None, scale=1.0, translate=(0.0, 0.0, 0.0)):

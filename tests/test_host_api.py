@@ -187,6 +187,26 @@ def test_host_builder_equals_the_python_builder_node_for_node(split_method, gold
             assert want["n_prims"].max() == 3
 
 
+def test_batch_constructor_equals_the_constructor_bit_for_bit(golden_dir):
+    """PreComputedTriangle.batch (what load_obj / triangles_from_mesh use: whole-array arithmetic) gives objects whose every
+    field -- homogeneous vertices, centroid, edges, unit normal, plane constant -- equals PreComputedTriangle(...)'s (pinned
+    by G6) bit for bit, degenerate triangles (NaN normals) included."""
+    g = np.load(os.path.join(golden_dir, "g10_obj_meshes.npz"))
+    v, f = g["cow_verts"], g["cow_faces"][:1500]
+    v1, v2, v3 = v[f[:, 0]].copy(), v[f[:, 1]].copy(), v[f[:, 2]].copy()
+    v3[7] = v1[7]; v2[11] = v1[11]; v3[11] = v1[11]            # a sliver with two equal vertices, a point
+    got = P.PreComputedTriangle.batch(v1, v2, v3, K.GLASS_MAT)
+    assert len(got) == 1500
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for i in range(1500):
+            want = P.PreComputedTriangle(v1[i], v2[i], v3[i], K.GLASS_MAT)
+            for k in ("vertex_1", "vertex_2", "vertex_3", "centroid", "edge_1", "edge_2", "normal"):
+                assert np.array_equal(getattr(got[i], k), getattr(want, k), equal_nan=True), (i, k)
+            assert got[i].num == want.num and got[i].type == want.type and got[i].material is want.material and got[i].is_light is False
+            assert np.array_equal(got[i].vertices3(), want.vertices3())
+    assert np.isnan(got[11].normal[:3]).all() and got[7].vertex_1.shape == (4,) and got[7].vertex_1[3] == 1.0
+
+
 def test_bvh_on_many_random_triangles():
     rs = np.random.RandomState(3)
     prims = [P.PreComputedTriangle(c + rs.normal(0, 0.2, 3), c + rs.normal(0, 0.2, 3), c + rs.normal(0, 0.2, 3), K.GLASS_MAT)
