@@ -523,8 +523,15 @@ def main(argv=None):
                 "k_log_reduce": every["reduce_ms"] / every["batches"],
                 "dispatches_per_kernel": every["batches"], "launches": every["launches"],
                 "note": "mean over EVERY dispatch this process made (probe, warm-up, timed, reference launches; sub-batches "
-                        "and pilot batches count as dispatches): the number a rocprofv3 --kernel-trace --stats summary of the "
-                        "same command reports as AverageNs (profiles/*_kernel_stats.csv); %s" % (
+                        "and pilot batches count as dispatches) of the HIP-event interval around the stage on its own stream.  "
+                        "Compare with AverageNs of a rocprofv3 --kernel-trace --stats summary of the same command "
+                        "(profiles/*_kernel_stats.csv) knowing what differs: an event interval also holds the time a kernel "
+                        "waits for CUs that other streams' kernels occupy, so with jobs / lanes in flight it EXCEEDS the "
+                        "kernel's own duration (measured, C2: walk 39.9 vs 38.0 ms, partition 13.7 vs 10.6, reduce 6.6 vs 4.2); "
+                        "for a job alone the two agree (roofline.one_job_alone).  walk_kernel here = the rows "
+                        "walk_kernel<.., 0> and <.., 1> there (whole walk / bulk of a split walk); the tail kernel <.., 2> "
+                        "runs on its own stream and is in no stage sum; k_log_part<.., false> / <.., true> (beside a walk / "
+                        "alone) are one stage here; %s" % (
                             "k_log_part<.,1,.> + k_log_count2 + k_log_part<.,2,.> are separate rows there (k_log_count1 belongs to the scan stage)" if passes_ == 2 else
                             "one partition dispatch per batch")}
         if alone:
