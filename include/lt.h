@@ -258,7 +258,9 @@ int lt_reduce_grid(lt_ctx* ctx, void* nccl_comm, int root);
 /* nearest hit of n rays against the ctx mesh -- role of hit_object /
  * intersect_bvh (utils.py:53-68, bvh_new.py:414-482), predicate
  * EPSILON < t < tmax.  prim_out = -1, t_out = +inf when nothing is hit.
- * use_bvh = 0: brute force over all triangles. */
+ * use_bvh = 0: brute force over all triangles; 1: the flattened BVH; 2: the march grid as the walk uses it for meshes beyond
+ * LDS (wave-cooperative: lanes march their rays through the grid, the whole wave tests the candidates; built on request for
+ * smaller meshes); 3: the same march lane by lane.  All four give the same answer bit for bit. */
 int lt_intersect_rays(lt_ctx* ctx, const double* origins, const double* dirs,
                       const double* tmax, size_t n, int use_bvh, int32_t* prim_out,
                       double* t_out);

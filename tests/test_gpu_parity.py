@@ -510,6 +510,16 @@ def test_large_mesh_in_global_memory(ctx):
     check_counters(c, co, n)
     assert int((fx != fxo).sum()) == 0
     assert c["w_escaped_mesh"] > 0 and fx.sum() > 0
+    # the f32 walk through the same mesh (walk_kernel_m<float>: 32-bit hit slots, f32 march)
+    # against the oracle's f32 restatement on the same XORWOW streams, as test_f32_walk_parity does for the slab
+    n32 = 100000
+    g32, c32 = run_gpu(ctx, prob, n32, dtype="f32", seed=9, f32_walk=True)
+    go32, _, co32 = prob.oracle().run(n32, seed=9, threads=8, walk_f32=True)
+    assert abs(O.conservation_residual(c32)) < 2e-5 * n32
+    assert abs(c32["steps"] - co32["steps"]) / co32["steps"] < 2e-3
+    for k in ("w_absorbed", "w_escaped_mesh", "w_lost_outside_grid"):
+        assert abs(c32[k] - co32[k]) / n32 < 2e-3, (k, c32[k], co32[k])
+    assert np.abs(g32 - go32).sum() / go32.sum() < 2e-2
 
 
 def test_integration_md_stub_runs_as_written(ctx):
