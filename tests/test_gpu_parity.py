@@ -321,14 +321,48 @@ def test_c3_c4_full_size_properties(ctx, name):
         m = 2 * 10 ** 6
         ctx.zero_tally(); ctx.launch(m, seed=4); ctx.sync()
         a, ca = ctx.read_grid_raw(), ctx.read_counters()
-        os.environ["LT_NO_CLEARANCE"] = "1"
-        try:
+        assert ctx.mesh_accel_info()["kind"] == 1              # (the run above used the clearance grid with near-triangle lists)
+        with ctx.tuning(no_clearance=1):                       # every step queries the BVH
             prob.apply(ctx, "u64fx"); ctx.set_tally_mode("atomic")
             ctx.launch(m, seed=4); ctx.sync()
-        finally:
-            os.environ.pop("LT_NO_CLEARANCE", None)
+            assert ctx.mesh_accel_info()["kind"] == 0          # ... and this one really ran without it
         assert np.array_equal(a, ctx.read_grid_raw()) and ctx.read_counters()["steps"] == ca["steps"]
         prob.apply(ctx, "u64fx")      # (tables with the clearance grid again for whoever uses the session ctx next)
+    ctx.set_tally_mode(2)
+
+
+def test_large_mesh_full_size_properties(ctx, golden_dir):
+    """The reference's teapot (6320 triangles + box: march grid, walk_kernel_m) at the BASELINE size -- 1e7 photons, 256^3:
+    energy conservation; one launch == three ragged shards; log tally == atomic tally; and, at 2e6 photons, == the walk
+    with the march grid switched off (walk_kernel_q over the BVH) -- u64 fixed point, bit for bit.  At this size every
+    wave's candidate queue drains tens of thousands of times under every interleaving of marching, waiting and resolved
+    lanes: what a 20 000-photon parity run against the oracle cannot exercise."""
+    g = load(golden_dir, "g10_obj_meshes.npz")
+    prob = S.obj_in_box(g["teapot_verts"], g["teapot_faces"], n=256)[0]
+    n = 10 ** 7
+    prob.apply(ctx, "u64fx"); ctx.set_tally_mode("log")
+    ctx.launch(n, seed=3); ctx.sync()
+    whole, c = ctx.read_grid_raw(), ctx.read_counters()
+    assert ctx.mesh_accel_info()["kind"] & 2 and ctx.last_log_info() is not None
+    assert c["photons"] == n and abs(O.conservation_residual(c)) < 1e-9 * n
+    assert abs(float(whole.sum()) / O.FX_SCALE - c["w_absorbed"]) < 1e-6 * n
+    assert 38 < c["steps"] / n < 48 and c["w_escaped_mesh"] > 0.3 * n
+    ctx.zero_tally()
+    for off, cnt in ((0, 2345678), (2345678, 4000001), (6345679, n - 6345679)):
+        ctx.launch(cnt, seed=3, photon_offset=off)
+    ctx.sync()
+    assert np.array_equal(whole, ctx.read_grid_raw()) and ctx.read_counters()["steps"] == c["steps"]
+    prob.apply(ctx, "u64fx"); ctx.set_tally_mode("atomic")
+    ctx.launch(n, seed=3); ctx.sync()
+    assert np.array_equal(whole, ctx.read_grid_raw()) and ctx.read_counters()["steps"] == c["steps"]
+    m = 2 * 10 ** 6
+    ctx.zero_tally(); ctx.launch(m, seed=4); ctx.sync()
+    a, ca = ctx.read_grid_raw(), ctx.read_counters()
+    with ctx.tuning(no_march=1):
+        prob.apply(ctx, "u64fx"); ctx.set_tally_mode("atomic")
+        ctx.launch(m, seed=4); ctx.sync()
+        assert ctx.mesh_accel_info()["kind"] == 0
+    assert np.array_equal(a, ctx.read_grid_raw()) and ctx.read_counters()["steps"] == ca["steps"]
     ctx.set_tally_mode(2)
 
 
