@@ -501,8 +501,9 @@ def test_fluence_quantity(ctx):
 
 # ---------------------------------------------------------------- f1: meshes beyond the LDS budget, SAH builder
 def test_large_mesh_in_global_memory(ctx):
-    """5140 triangles / ~10^4 nodes (~1.2 MB of tables): traversed in place in global memory (GEOM 2),
-    built with the binned-SAH splitter.  Nearest hits: BVH == brute force == oracle; walk: bit-exact tally."""
+    """5140 triangles / ~10^4 nodes (~1.2 MB of tables, beyond the LDS budget): tables in global memory, surface queries
+    through the march grid (walk_kernel_m), built with the binned-SAH splitter.  Nearest hits: BVH == brute force == march
+    (both forms) == oracle; walk: bit-exact tally; the f32 walk against the oracle's f32 walk."""
     prob, ordered, linear = S.sphere_in_box(4, split_method=0)
     assert len(ordered) == 5140
     from light_transport_amd.src import bvh_new as B
