@@ -14,7 +14,11 @@ of constants, resident in HBM before the timed region).
 
 Workloads (BASELINE.json configs):
   c2 (default)  1e7 photons per GPU, homogeneous semi-infinite slab, 256^3 grid -- the config the metric is quoted on
+  c3            1e7 photons, two-layer skin model, 256^3 grid (0.05 mm)
+  c4            1e7 photons, Cornell cavity + cone (30 triangles, BVH), 256^3 grid, cosine source on the ceiling quad
   c5            1.25e7 photons per GPU (the per-GPU share of 1e8 over 8), two-layer skin model, 512^3 grid (1 GiB f64)
+The default run (c2, N = 1) measures c3, c4 and c5 AFTER the headline's timed region as well and reports them as flat
+roofline.cN_* keys (--extras): jobs in flight, one launch alone, its kernels, the CPU oracle beside each.
 
 Regimes (how a rank keeps its GPU busy; results are identical):
   one_call      ONE context; every lt_launch is cut into sub-batches that alternate between the context's two lanes, so
@@ -53,10 +57,19 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 INF = float("inf")
+# BASELINE.json configs (sizes and media: SURVEY.md 8(d)).  scene = "layers" (z_bounds, medium_idx) or "cornell" (the
+# reference's Cornell cube + cone, nb:LTS#11-16: 30 triangles, BVH, cosine source on the ceiling light quad).
 WORKLOADS = {
     "c2": dict(photons=10 ** 7, grid=256, voxel=0.1, media=[(0.1, 10.0, 0.9, 1.0)], z_bounds=[0.0, INF], medium_idx=[0],
                text="C2: %.0e photons per GPU, homogeneous semi-infinite slab (mu_a=0.1, mu_s=10, g=0.9, n=1), %d^3 voxel grid "
                     "(%.3g mm), pencil beam"),
+    "c3": dict(photons=10 ** 7, grid=256, voxel=0.05, media=[(0.43, 10.7, 0.79, 1.5), (0.27, 18.7, 0.82, 1.4)],
+               z_bounds=[0.0, 0.1, INF], medium_idx=[0, 1],
+               text="C3: %.0e photons per GPU, two-layer skin model (epidermis 0.1 mm n=1.5 / dermis n=1.4, air above), %d^3 voxel "
+                    "grid (%.3g mm), pencil beam"),
+    "c4": dict(photons=10 ** 7, grid=256, voxel=15.0 / 256, media=[(0.1, 10.0, 0.9, 1.0), (1.0, 5.0, 0.8, 1.5)], cornell=7.5,
+               text="C4: %.0e photons per GPU, Cornell cavity (half-width 7.5, C2's medium) + 10-triangle cone of a second medium "
+                    "(n=1.5): 30 triangles + BVH, %d^3 voxel grid (%.3g), cosine source on the 2x2 ceiling quad"),
     "c5": dict(photons=12500000, grid=512, voxel=0.025, media=[(0.43, 10.7, 0.79, 1.5), (0.27, 18.7, 0.82, 1.4)],
                z_bounds=[0.0, 0.1, INF], medium_idx=[0, 1],
                text="C5 per-GPU share: %.3g photons per GPU (1e8 over 8 GPUs), two-layer skin model (epidermis 0.1 mm n=1.5 / "
@@ -65,14 +78,49 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_STEP = {"f32": 8, "f64": 16, "u64fx": 16}
 REC_VALUE_BYTES = {"f32": 4, "f64": 8, "u64fx": 8}
+_MESH = {}
+
+
+def cornell_mesh(dim):
+    """Config 4's geometry from the package's own mirror of the reference's scene builders (src/cornell_box.py,
+    src/bvh_new.py): walls face the cavity (front = medium 0, back = exterior), the cone's faces point outwards."""
+    if dim not in _MESH:
+        from light_transport_amd.src import bvh_new as B, constants as K, cornell_box as cb
+        walls = (cb.get_cornell_box(dim, K.GLASS_MAT, K.GLASS_MAT, K.GLASS_MAT) + cb.get_front_wall(dim, K.GLASS_MAT)
+                 + cb.get_light_quad(dim, K.GLASS_MAT))
+        cone = cb.get_cone(K.GLASS_MAT)
+        for t in walls:
+            t.med_front, t.med_back = 0, -1
+        for t in cone:
+            t.med_front, t.med_back = 0, 1
+        ordered, linear = B.build_linear_bvh(walls + cone, 1)
+        _MESH[dim] = dict(verts=B.triangles_array(ordered), med_front=np.array([t.med_front for t in ordered], np.int32),
+                          med_back=np.array([t.med_back for t in ordered], np.int32), nodes=B.linear_bvh_arrays(linear))
+    return _MESH[dim]
+
+
+def grid_origin(wl):
+    half = wl["grid"] * wl["voxel"] / 2
+    return (-half, -half, -half) if "cornell" in wl else (-half, -half, 0.0)
+
+
+def source_of(wl):
+    if "cornell" in wl:
+        d = wl["cornell"]
+        return dict(type=1, pos=(-1.0, d, -1.0), dir=(0.0, -1.0, 0.0), extra=(2.0, 0.0, 0.0, 0.0, 0.0, 2.0), start_medium=0)
+    return dict(type=0, pos=(0.0, 0.0, 0.0), dir=(0.0, 0.0, 1.0), extra=None, start_medium=0)
 
 
 def configure(ctx, wl, tally):
-    half = wl["grid"] * wl["voxel"] / 2
     ctx.set_media(wl["media"])
-    ctx.set_layers(wl["z_bounds"], wl["medium_idx"], 1.0, 1.0)
-    ctx.set_grid((wl["grid"],) * 3, (-half, -half, 0.0), (wl["voxel"],) * 3, tally)
-    ctx.set_source(0, (0.0, 0.0, 0.0), (0.0, 0.0, 1.0))
+    if "cornell" in wl:
+        m = cornell_mesh(wl["cornell"])
+        ctx.set_mesh(m["verts"], m["med_front"], m["med_back"], m["nodes"])
+    else:
+        ctx.set_layers(wl["z_bounds"], wl["medium_idx"], 1.0, 1.0)
+    ctx.set_grid((wl["grid"],) * 3, grid_origin(wl), (wl["voxel"],) * 3, tally)
+    s_ = source_of(wl)
+    ctx.set_source(s_["type"], s_["pos"], s_["dir"], s_["extra"], s_["start_medium"])
 
 
 def kernel_sources_sha():
@@ -108,9 +156,13 @@ def cpu_baseline(wl, wl_name, target_seconds=12.0):
     """CPU oracle (port) on every host core, bounded sample of the workload."""
     from oracle import oracle as O
     cores = effective_cores()
-    half = wl["grid"] * wl["voxel"] / 2
-    sc = O.OracleScene(wl["media"], (wl["grid"],) * 3, (-half, -half, 0.0), (wl["voxel"],) * 3,
-                       layers=dict(z_bounds=wl["z_bounds"], medium_idx=wl["medium_idx"]))
+    if "cornell" in wl:
+        src = source_of(wl)
+        sc = O.OracleScene(wl["media"], (wl["grid"],) * 3, grid_origin(wl), (wl["voxel"],) * 3, mesh=cornell_mesh(wl["cornell"]),
+                           source=dict(src, extra=src["extra"] or (0.0,) * 6))
+    else:
+        sc = O.OracleScene(wl["media"], (wl["grid"],) * 3, grid_origin(wl), (wl["voxel"],) * 3,
+                           layers=dict(z_bounds=wl["z_bounds"], medium_idx=wl["medium_idx"]))
     t0 = time.perf_counter()
     _, _, c = sc.run(50000, seed=0, threads=cores)
     probe = time.perf_counter() - t0
@@ -179,6 +231,82 @@ def self_launch(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+def measure_extra(name, make_ctx, args, cpu_seconds):
+    """One more BASELINE config after the headline's timed region (single GPU): flat keys for the JSON line.
+    (a) throughput: two contexts take whole jobs in turn, walks at half of the resident workgroups each (the two_jobs regime);
+    (b) latency: ONE lt_launch alone, library defaults (what a trace_photons caller gets);
+    (c) its kernels on one lane, nothing beside them (tail split off: the per-kernel figures);
+    (d) the CPU oracle on the same workload, bounded sample."""
+    wl = WORKLOADS[name]
+    n = wl["photons"]
+    half = 3 if args.f32_walk else 2
+    cs = []
+    try:
+        for _ in range(2):
+            c = make_ctx()
+            configure(c, wl, args.tally)
+            c.set_tally_mode(args.tally_mode); c.set_overlap(1); c.set_launch_config(half, 256)
+            if args.tally_mode != "atomic":
+                c.reserve_log(n)
+            cs.append(c)
+
+        def jobs(k, seed0):
+            steps = 0
+            for c in cs:
+                c.sync()
+            t0 = time.perf_counter()
+            for j in range(k):
+                c = cs[j % 2]
+                if j >= 2:
+                    c.sync(); steps += c.read_counters()["steps"]
+                c.zero_tally(); c.launch(n, seed=seed0 + j, f32_walk=args.f32_walk)
+            for j in range(max(0, k - 2), k):
+                c = cs[j % 2]
+                c.sync(); steps += c.read_counters()["steps"]
+            return (time.perf_counter() - t0) / k * 1e3, steps / k
+        jobs(4, 700)                      # pilot batch of the scene, log sizing, warm-up
+        ms, steps = jobs(8, 710)
+        out = {name + "_ms": ms, name + "_steps_per_s": steps / (ms * 1e-3), name + "_photons_per_s": n / (ms * 1e-3),
+               name + "_frac": steps * BYTES_PER_STEP[args.tally] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, name + "_regime": "two_jobs",
+               name + "_steps_per_job": steps}
+        cs.pop().close()
+        c = cs[0]
+        c.set_launch_config(0, 0); c.set_overlap(0)
+        t_ = []
+        for k in range(6):                # overlap auto settles over the first launches (one lane / two lanes, keeps the faster)
+            c.zero_tally(); c.launch(n, seed=720 + k, f32_walk=args.f32_walk); c.sync()
+            t_.append(c.last_kernel_ms())
+        info = c.last_log_info()
+        out[name + "_one_launch_ms"] = float(np.mean(t_[3:]))
+        out[name + "_one_launch_steps_per_s"] = steps / (out[name + "_one_launch_ms"] * 1e-3)
+        out[name + "_one_launch_lanes"] = info["lanes"] if info else 1
+        c.set_overlap(1); c.set_tuning("tail_split", 0)
+        st, t1 = None, []
+        for k in range(3):
+            c.zero_tally(); c.launch(n, seed=730 + k, f32_walk=args.f32_walk); c.sync()
+            t1.append(c.last_kernel_ms()); st = c.last_log_stages()
+        c.set_tuning("tail_split", -1)
+        out[name + "_alone_job_ms"] = float(np.mean(t1[1:]))
+        if st:
+            rec, rb_ = st["records"], 4 + REC_VALUE_BYTES[args.tally]
+            for k_ in ("walk_ms", "scan_ms", "partition_ms", "reduce_ms"):
+                out["%s_alone_%s" % (name, k_)] = st[k_]
+            out[name + "_records_per_job"] = rec
+            two_pass = wl["grid"] ** 3 > 1024 * 16384
+            p_ = st["partition_ms"] + (st["scan_ms"] if two_pass else 0.0)
+            if p_ > 0 and st["reduce_ms"] > 0:
+                out[name + "_partition_frac"] = rec * (2 * rb_ - 2) / (p_ * 1e-3) / 1e9 / HBM_PEAK_GBS
+                out[name + "_reduce_frac"] = rec * (rb_ - 2) / (st["reduce_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out[name + "_walk_steps_per_s"] = steps / (st["walk_ms"] * 1e-3)
+    finally:
+        for c in cs:
+            c.close()
+    if cpu_seconds:
+        cb = cpu_baseline(wl, name, target_seconds=cpu_seconds)
+        out[name + "_cpu_steps_per_s"], out[name + "_cpu_cores"], out[name + "_cpu_sample"] = cb["value"], cb["cores"], cb["sample"]
+    return out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +330,10 @@ def main(argv=None):
                     help="skip the single-job reference launches and the readback after the timed region (keeps a rocprofv3 "
                          "kernel trace of this command to launches of the timed regime only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", default="auto",
+                    help="BASELINE configs measured AFTER the timed region (N = 1 only; each: jobs in flight, one launch alone, "
+                         "its kernels, the CPU oracle) and reported as flat roofline.cN_* keys: 'auto' = c3,c4,c5 for the default "
+                         "c2 run, 'none', or a comma-separated list")
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)        # tests: gloo
     ap.add_argument("--ctx-factory", default="", help=argparse.SUPPRESS)        # tests: module:callable returning a recording ctx
     args = ap.parse_args(argv)
@@ -329,15 +461,21 @@ def main(argv=None):
                 continue
             cs = apply_regime(name)
             run_jobs(cs, len(cs), 900)                    # sizes the logs, pilot batch of a new scene
-            # 12 jobs per regime: enough that the pipeline's fill and drain (a third of a 6-job probe with three jobs in
-            # flight) no longer decide between regimes that differ by a millisecond per job
-            probe[name + "_ms"] = run_jobs(cs, max(12, 4 * len(cs)), 910)
+            # jobs in flight: 24 jobs (0.9 s), so that the pipeline's fill and drain -- a third of a 6-job probe with three
+            # jobs in flight -- weigh under 2 % and regimes a millisecond apart are told apart; the one-context regimes
+            # (never within 5 % of the winners) get 8
+            probe[name + "_ms"] = run_jobs(cs, 24 if len(cs) > 1 else 8, 910)
         if distributed:     # every rank must take the same path: the collectives are issued per context in turn
             for k in sorted(probe):
                 t = dev.scalar(probe[k], torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 probe[k] = float(t.item())
         regime = min(REGIMES, key=lambda r: probe[r + "_ms"])
+        # Tie rule.  three_jobs is the steady-state winner wherever the runtime gives its streams their own hardware queues
+        # (34.4-35.4 ms against 35.7-36.4 with two) and it hides more of every job's drain, but a short probe can
+        # put the two within noise of each other on either side: it keeps three_jobs unless two_jobs wins by more than 1.5 %.
+        if regime == "two_jobs" and "three_jobs" in REGIMES and probe["three_jobs_ms"] <= 1.015 * probe["two_jobs_ms"]:
+            regime = "three_jobs"
         probe["chosen"] = regime
     ctxs = apply_regime(regime)
     depth, lanes = REGIMES[regime]
@@ -388,10 +526,18 @@ def main(argv=None):
     barrier()
     elapsed = time.perf_counter() - t0
 
+    # How much of each job overlapped with its neighbours ON THIS RANK: span of a job's own HIP events (first kernel to
+    # last) / wall time per job.  ~1: the jobs ran one after the other -- with depth >= 2 that means this rank's streams
+    # shared a hardware queue (or the device was otherwise serialised); ~depth: they really were in flight together.
+    own_overlap = float(np.mean(kernel_ms)) / (elapsed / args.steps * 1e3) if kernel_ms else 0.0
+    overlap_ranks = [own_overlap]
     if distributed:
         t = dev.scalar(elapsed, torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ov = [dev.scalar(0.0, torch.float64) for _ in range(world)]
+        dist.all_gather(ov, dev.scalar(own_overlap, torch.float64))
+        overlap_ranks = [float(x.item()) for x in ov]
         km = dev.scalar(float(np.mean(kernel_ms)), torch.float64)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
         kernel_avg_ms = float(km.item())
@@ -545,8 +691,55 @@ def main(argv=None):
                                "note": "D2H of the raw grid into pinned host memory (one rank), outside the timed region",
                                "photon_steps_per_sec_incl_readback": steps_one_launch / ((launch_ms + readback_ms) * 1e-3),
                                "photons_per_sec_incl_readback": per_gpu / ((launch_ms + readback_ms) * 1e-3)}
+        # ---- flat scalar copies of what the nested objects above hold (a consumer that keeps only scalar keys of
+        # config / roofline still sees the probe, the kernels of one job alone and the stream overlap)
+        cfg, rf = out["config"], out["roofline"]
+        if probe:
+            for k_, v_ in probe.items():
+                cfg["probe_" + k_] = v_
+        cfg["overlap_factor_min"], cfg["overlap_factor_max"] = min(overlap_ranks), max(overlap_ranks)
+        cfg["overlap_factor_per_rank"] = ",".join("%.2f" % x for x in overlap_ranks)
+        # a rank whose jobs in flight did not overlap (factor < 1.3 where depth >= 2 promises ~depth): its streams were serialised
+        cfg["serialised_ranks"] = sum(1 for x in overlap_ranks if depth >= 2 and x < 1.3)
+        cfg["gpu_max_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "")
+        tag = args.workload
+        rf[tag + "_steps_per_s"], rf[tag + "_ms"], rf[tag + "_frac"], rf[tag + "_regime"] = value / world, ms_per_step, achieved / HBM_PEAK_GBS, regime
+        if alone:
+            for k_ in ("job_ms", "job_ms_shipping_default", "walk_ms", "scan_ms", "partition_ms", "reduce_ms"):
+                if k_ in alone:
+                    rf["%s_alone_%s" % (tag, k_)] = alone[k_]
+            if "job_ms_shipping_default" in alone:
+                rf[tag + "_one_launch_ms"] = alone["job_ms_shipping_default"]
+                rf[tag + "_one_launch_steps_per_s"] = steps_one_launch / (alone["job_ms_shipping_default"] * 1e-3)
+        for kr in rf.get("kernels", []):
+            if "frac" in kr:
+                rf["%s_%s_frac" % (tag, "partition" if "part" in kr["kernel"] else "reduce")] = kr["frac"]
+        if readback_ms is not None:
+            rf[tag + "_readback_ms"] = readback_ms
+        cpu = None
         if not args.no_cpu_baseline and world == 1 and not fake:
-            out["cpu_baseline"] = cpu_baseline(wl, args.workload)
+            cpu = out["cpu_baseline"] = cpu_baseline(wl, args.workload)
+            rf[tag + "_cpu_steps_per_s"] = cpu["value"]
+        # ---- the other BASELINE configs (N = 1): their contexts come after this workload's have given their logs back
+        extras = [] if (world != 1 or fake or distributed) else (
+            [x for x in ("c3", "c4", "c5") if x != args.workload] if args.extras == "auto" and args.workload == "c2" and not args.photons
+            else [x for x in args.extras.split(",") if x in WORKLOADS and x != args.workload] if args.extras not in ("auto", "none") else [])
+        if extras:
+            for c in pool:
+                c.close()
+            pool[:] = []
+            for name in extras:
+                try:
+                    ex = measure_extra(name, make_ctx, args, 0 if args.no_cpu_baseline else 3.0)
+                except Exception as e:      # an extra must never cost the headline its line
+                    ex = {name + "_error": "%s: %s" % (type(e).__name__, str(e)[:160])}
+                rf.update(ex)
+                if cpu is not None and name + "_cpu_steps_per_s" in ex:
+                    cpu[name + "_value"] = ex[name + "_cpu_steps_per_s"]
+            rf["extras_note"] = ("cN_steps_per_s / cN_ms / cN_frac: whole jobs with two in flight (8 timed after 4 untimed, host clock "
+                                 "between syncs), frac = 16 B x photon-steps / ms / 8 TB/s; cN_one_launch_*: one lt_launch alone with the "
+                                 "library's defaults (mean of 3, device time); cN_alone_*: that launch's kernels on one lane with nothing "
+                                 "beside them; cN_cpu_steps_per_s: the CPU oracle on cN_cpu_cores threads, a ~3 s sample")
         print(json.dumps(out))
     if distributed:
         dist.barrier()
