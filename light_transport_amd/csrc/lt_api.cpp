@@ -117,7 +117,7 @@ struct lt_ctx {
     int blocks_per_cu = 0, threads_per_block = 0;
 
     // device buffers
-    DevBuf d_media[2], d_zb[2], d_lm, d_tris[2], d_nodes[2];  // [0]=f64, [1]=f32
+    DevBuf d_media[2], d_zb[2], d_if[2], d_lm, d_tris[2], d_nodes[2];  // [0]=f64, [1]=f32
     DevBuf d_grid, d_counters, d_head, d_table, d_scratch_in, d_scratch_out, d_scratch_aux;
     DevBuf d_mats, d_lights, d_r0, d_r1, d_lc, d_img, d_xy, d_vtx, d_vcnt, d_clear, d_job, d_gridx[kMaxLanes - 1];   // d_gridx: private grids of lanes 1, 2
     int cn[3] = {0, 0, 0};
@@ -140,7 +140,7 @@ struct lt_ctx {
     struct Knobs {
         long query_min = -1, log_bits2 = -1, log_hot = -1, overlap_walk_bpc = -1, diag_no_tally = -1, log_timing = -1,
              march_cells = -1, march_scale_milli = -1, no_march = -1, no_clearance = -1, no_near_lists = -1,
-             clearance_cells = -1, march_info = -1, force_march = -1, tail_split = -1;
+             clearance_cells = -1, march_info = -1, force_march = -1, tail_split = -1, part_alone = -1;
         std::string overlap_pattern;      // LT_OVERLAP_PATTERN (relative sub-batch sizes; tools/pattern_ab.py)
     } knob;
     long* knob_by_name(const char* key)
@@ -150,7 +150,7 @@ struct lt_ctx {
             {"overlap_walk_bpc", &Knobs::overlap_walk_bpc}, {"diag_no_tally", &Knobs::diag_no_tally}, {"log_timing", &Knobs::log_timing},
             {"march_cells", &Knobs::march_cells}, {"march_scale_milli", &Knobs::march_scale_milli}, {"no_march", &Knobs::no_march},
             {"no_clearance", &Knobs::no_clearance}, {"no_near_lists", &Knobs::no_near_lists}, {"clearance_cells", &Knobs::clearance_cells},
-            {"march_info", &Knobs::march_info}, {"force_march", &Knobs::force_march}, {"tail_split", &Knobs::tail_split}};
+            {"march_info", &Knobs::march_info}, {"force_march", &Knobs::force_march}, {"tail_split", &Knobs::tail_split}, {"part_alone", &Knobs::part_alone}};
         for (const auto& t : tab) if (std::strcmp(key, t.k) == 0) return &(knob.*(t.m));
         return nullptr;
     }
@@ -252,6 +252,25 @@ void fill_nodes(const std::vector<lt_bvh_node>& in, std::vector<NodeD<R>>& out)
         if (in[i].n_prims > 0) continue;
         out[i + 1].skip = in[i].offset;
         out[(size_t)in[i].offset].skip = out[i].skip;
+    }
+}
+
+// interface table of a layered slab (IfD): the indices either side of every plane and their quotients, one IEEE operation
+// each in walk precision (this file is built with -ffp-contract=off) -- what the oracle computes per event as n1 / n2
+template <typename R>
+void fill_ifaces(const lt_ctx* c, std::vector<IfD<R>>& out)
+{
+    const int n = (int)c->layer_medium.size();
+    out.resize((size_t)n + 1);
+    for (int k = 0; k <= n; k++) {
+        auto index_of = [&](int layer) {     // (an index beyond the media table is refused by lt_launch; this only keeps the read in bounds)
+            const int32_t m = c->layer_medium[(size_t)layer];
+            return m >= 0 && (size_t)m < c->media.size() ? c->media[(size_t)m].n : 1.0;
+        };
+        const R up = (R)(k == 0 ? c->n_above : index_of(k - 1));
+        const R dn = (R)(k == n ? c->n_below : index_of(k));
+        out[(size_t)k].n_up = up; out[(size_t)k].n_dn = dn;
+        out[(size_t)k].nr_down = up / dn; out[(size_t)k].nr_up = dn / up;
     }
 }
 
@@ -394,11 +413,17 @@ int upload_tables(lt_ctx* c)
     // staging vectors live until the stream has drained (pageable H2D copies)
     std::vector<MedD<double>> m64; std::vector<MedD<float>> m32;
     std::vector<double> z64; std::vector<float> z32;
+    std::vector<IfD<double>> i64; std::vector<IfD<float>> i32;
     std::vector<TriD<double>> t64; std::vector<TriD<float>> t32;
     std::vector<NodeD<double>> n64; std::vector<NodeD<float>> n32;
     fill_media(c->media, c->quantity, m64); fill_media(c->media, c->quantity, m32);
     if ((rc = upload(c, c->d_media[0], m64))) return rc;
     if ((rc = upload(c, c->d_media[1], m32))) return rc;
+    if (c->have_layers) {      // (layer -> medium indices are checked against the media table by lt_launch before it comes here)
+        fill_ifaces(c, i64); fill_ifaces(c, i32);
+        if ((rc = upload(c, c->d_if[0], i64))) return rc;
+        if ((rc = upload(c, c->d_if[1], i32))) return rc;
+    }
     if (!c->tables_dirty) {      // only the media table changed (lt_set_tally_quantity): the geometry tables stay
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->media_dirty = false;
@@ -739,9 +764,6 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         L.grid = bt.first >= 1 ? c->d_gridx[bt.first - 1].p : c->d_grid.p; L.n_vox = c->n_vox(); L.tally = c->tally;
         L.nx = (uint32_t)c->nx; L.ny = (uint32_t)c->ny; L.nz = (uint32_t)c->nz; L.ntx = G.ntx; L.nty = G.nty;
         L.flush_atomic = 0;
-        // one lane AND the caller has not asked for a walk at partial occupancy (lt_set_launch_config: what a host that keeps
-        // several contexts in flight does, bench.py's two_jobs / three_jobs): then nothing co-runs with this reduction
-        L.alone = (plan.lanes == 1 && c->blocks_per_cu == 0) ? 1 : 0;
         if (hot) { L.dmap = (const uint16_t*)c->d_dmap.p; L.dmeta = (const uint32_t*)c->d_dmeta.p; }
 
         HIP_TRY(c, hipMemsetAsync(ln.head.p, 0, sizeof(unsigned long long), s));
@@ -766,6 +788,12 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
                            // (one lane, f32 walk: measured a LOSS -- 28.9 -> 31.6 ms on C2: the partition beside the tail kernel takes
                            //  3 ms longer and the f32 drain is short -- so it is left out there.)  (A host that runs walks at
                            // partial occupancy keeps several contexts in flight: their drains are hidden already, a tail kernel only adds contention)
+        // alone: one lane AND the caller has not asked for a walk at partial occupancy (lt_set_launch_config: what a host that
+        // keeps several contexts in flight does, bench.py's two_jobs / three_jobs): then nothing co-runs with this reduction
+        // (a split batch is NOT alone: its tail kernel walks beside the partition and the reduce -- ADVICE r3; the knob
+        // part_alone = 0 / 1 pins the build for A/B runs)
+        L.alone = (plan.lanes == 1 && c->blocks_per_cu == 0 && !split) ? 1 : 0;
+        if (c->knob.part_alone == 0 || c->knob.part_alone == 1) L.alone = (int)c->knob.part_alone;
         Variant vw = R.v;
         if (split) {
             const size_t cap = (size_t)cfg.blocks * (size_t)(cfg.threads / 64) * kDumpPoolLanes;      // every wave hands over at most that many
@@ -866,7 +894,7 @@ int lt_create(lt_ctx** out, int device_id)
     c->device = device_id;
     {   // the one place the environment is read: LT_QUERY_MIN, LT_LOG_HOT, ... seed the knobs of lt_set_tuning
         static const char* const names[] = {"query_min", "log_bits2", "log_hot", "overlap_walk_bpc", "diag_no_tally", "log_timing", "march_cells",
-                                            "march_scale_milli", "no_march", "no_clearance", "no_near_lists", "clearance_cells", "march_info", "force_march", "tail_split"};
+                                            "march_scale_milli", "no_march", "no_clearance", "no_near_lists", "clearance_cells", "march_info", "force_march", "tail_split", "part_alone"};
         for (const char* k : names) {
             std::string name = "LT_";
             for (const char* q = k; *q; q++) name += (char)std::toupper((unsigned char)*q);
@@ -910,7 +938,7 @@ int lt_destroy(lt_ctx* c)
     if (!c) return LT_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 2; i++) { c->d_media[i].release(); c->d_zb[i].release(); c->d_tris[i].release(); c->d_nodes[i].release(); }
+    for (int i = 0; i < 2; i++) { c->d_media[i].release(); c->d_zb[i].release(); c->d_if[i].release(); c->d_tris[i].release(); c->d_nodes[i].release(); }
     c->d_lm.release(); c->d_grid.release(); c->d_counters.release(); c->d_head.release(); c->d_table.release();
     c->d_scratch_in.release(); c->d_scratch_out.release(); c->d_scratch_aux.release();
     c->d_mats.release(); c->d_lights.release(); c->d_r0.release(); c->d_r1.release(); c->d_lc.release();
@@ -1122,7 +1150,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     P.head = (unsigned long long*)c->d_head.p;
     P.n_photons = n_photons; P.photon_offset = photon_offset; P.seed = seed;
     const int pi = v.f32 ? 1 : 0;
-    P.media = c->d_media[pi].p; P.zb = c->d_zb[pi].p; P.layer_medium = (const int32_t*)c->d_lm.p;
+    P.media = c->d_media[pi].p; P.zb = c->d_zb[pi].p; P.ifaces = c->d_if[pi].p; P.layer_medium = (const int32_t*)c->d_lm.p;
     P.tris = c->d_tris[pi].p; P.nodes = c->d_nodes[pi].p;
     P.n_media = n_media;
     P.n_layers = c->have_layers ? (int)c->layer_medium.size() : 0;

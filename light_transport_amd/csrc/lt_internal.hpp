@@ -18,6 +18,16 @@ struct MedD {
     R pad_;
 };
 
+// Plane interface k of a layered slab (between layer k - 1 above and layer k below; k = 0 / n_layers: the ambient media):
+// the refractive indices on both sides and their two quotients, computed once on the host (one IEEE division each, in walk
+// precision) instead of by every photon that reaches the plane -- the Fresnel block of S/path_tracing_fix1.py:86-119
+// runs whenever ANY lane of a wave sits on an interface, which in a layered medium is most wave-steps.
+template <typename R>
+struct IfD {
+    R n_up, n_dn;        // index above / below the plane
+    R nr_down, nr_up;    // n1 / n2 for a photon travelling down (n_up / n_dn) and up (n_dn / n_up)
+};
+
 // Triangle record: role of PreComputedTriangle (primitives.py:99-112).
 template <typename R>
 struct TriD {
@@ -99,6 +109,7 @@ struct WalkParams {
     // scene tables (device pointers, element type depends on walk precision)
     const void* media;
     const void* zb;
+    const void* ifaces;         // IfD<R>[n_layers + 1]
     const int32_t* layer_medium;
     const void* tris;
     const void* nodes;

@@ -36,6 +36,10 @@
 
 #include "lt_internal.hpp"
 
+// the tail split hands a photon's generator over as six words (SurvD::rng = {d, x[5]}): true only while the Box-Muller
+// cache is compiled out of the state (ROCRAND_DETAIL_BM_NOT_IN_STATE above) and the header keeps this layout
+static_assert(sizeof(rocrand_state_xorwow) == 6 * sizeof(uint32_t), "rocrand_state_xorwow is not {d, x[5]}: SurvD::rng and the tail-split hand-over assume it");
+
 namespace ltk {
 
 #define LT_DEV __device__ __forceinline__
@@ -724,6 +728,24 @@ template <typename R> LT_DEV R boundary(const R* d, const R* nf, R n1, R n2, R* 
     return (R)0.5 * (rs * rs + rp * rp);
 }
 
+// The same event at a PLANE z = const (layered slabs), where it specialises exactly: cos_i = |uz|; the reflected direction is
+// (ux, uy, -uz) -- v - 2 (v.n) n with n = (0, 0, +-1), no rounding at all; the refracted one is (Nr ux, Nr uy, sign(uz) cos_t),
+// of unit length by Snell's law (Nr^2 (1 - uz^2) + cos_t^2 = 1), so neither is renormalised.  n1 / n2 and Nr = n1 / n2 come
+// from the interface table (IfD).  Returns the unpolarised Fresnel reflectance; TIR (radicand <= 0, :110) returns 1.
+// oracle/lt_walk.inc: boundary_planar, the same operations with IEEE division and square root.
+template <typename R> LT_DEV R boundary_planar(R uz, R n1, R n2, R Nr, R* cos_t_out)
+{
+    const R cos_i = Mx<R>::abs(uz);
+    if (n1 == n2) { *cos_t_out = cos_i; return 0; }
+    const R rad = (R)1 - Nr * Nr * ((R)1 - cos_i * cos_i);
+    if (rad <= 0) { *cos_t_out = 0; return 1; }
+    const R cos_t = Mx<R>::sqrt_pos(rad);
+    const R a = n1 * cos_i, b = n2 * cos_t, c = n1 * cos_t, e = n2 * cos_i;
+    const R rs = Mx<R>::quot(a - b, a + b), rp = Mx<R>::quot(c - e, c + e);
+    *cos_t_out = cos_t;
+    return (R)0.5 * (rs * rs + rp * rp);
+}
+
 // Spin (App. C.6): MCML direction update, |uz| > 0.99999 special case.
 template <typename R> LT_DEV void spin(R* u, R ct, R xi_phi)
 {
@@ -800,7 +822,7 @@ template <int TALLY> LT_DEV void tally_add(void* grid, unsigned idx, typename Ta
 LT_DEV size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 template <typename R> struct LdsLayout {
-    size_t off_cnt, off_media, off_zb, off_lm, off_tris, off_nodes, off_hist, off_march, total;
+    size_t off_cnt, off_media, off_zb, off_if, off_lm, off_tris, off_nodes, off_hist, off_march, total;
     __host__ __device__ LdsLayout(int n_media, int n_layers, int n_tris, int n_nodes, unsigned n_hist = 0, size_t march_bytes = 0)
     {
         auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -808,6 +830,7 @@ template <typename R> struct LdsLayout {
         off_cnt = o;   o = al(o + 8 * sizeof(double));
         off_media = o; o = al(o + (size_t)n_media * sizeof(MedD<R>));
         off_zb = o;    o = al(o + (size_t)(n_layers + 1) * sizeof(R));
+        off_if = o;    o = al(o + (size_t)(n_layers > 0 ? n_layers + 1 : 0) * sizeof(IfD<R>));
         off_lm = o;    o = al(o + (size_t)(n_layers > 0 ? n_layers : 1) * sizeof(int32_t));
         off_tris = o;  o = al(o + (size_t)n_tris * sizeof(TriD<R>));
         off_nodes = o; o = al(o + (size_t)n_nodes * sizeof(NodeD<R>));
@@ -1049,9 +1072,10 @@ size_t walk_lds_bytes(const Variant& v, int n_media, int n_layers, int n_tris, i
 {
     if (v.mesh) n_layers = 0;
     if (v.mesh != 1) { n_tris = 0; n_nodes = 0; }
-    // GEOM 2: the march service's per-wave scratch (rays, best hits, candidate queue), four waves per workgroup
-    return v.f32 ? LdsLayout<float>(n_media, n_layers, n_tris, n_nodes, n_hist, v.mesh >= 2 ? 4 * sizeof(MarchWave<float>) : 0).total
-                 : LdsLayout<double>(n_media, n_layers, n_tris, n_nodes, n_hist, v.mesh >= 2 ? 4 * sizeof(MarchWave<double>) : 0).total;
+    // walk_kernel_m (mesh 3): the march's per-wave scratch (rays, best hits, candidate queue), four waves per workgroup.  The
+    // plain global-memory kernel (mesh 2: no march grid / LT_NO_MARCH) never touches it and keeps its LDS free
+    return v.f32 ? LdsLayout<float>(n_media, n_layers, n_tris, n_nodes, n_hist, v.mesh == 3 ? 4 * sizeof(MarchWave<float>) : 0).total
+                 : LdsLayout<double>(n_media, n_layers, n_tris, n_nodes, n_hist, v.mesh == 3 ? 4 * sizeof(MarchWave<double>) : 0).total;
 }
 
 int walk_max_blocks_per_cu(const Variant& v, int threads, size_t lds_bytes)

@@ -189,10 +189,21 @@ def build_linear_bvh(primitives, split_method=1):
     The tree is built by the library's host builder (lt_build_bvh, C++: milliseconds where the recursion above takes
     seconds on the reference's 10 000-triangle pumpkin) and handed back as LinearBVHNode objects; it equals
     build_bvh + flatten_bvh above node for node (tests/test_host_api.py), so either route gives the same ordered_prims."""
-    from .._lib import build_bvh_arrays
+    from .._lib import LtError, build_bvh_arrays
     if not len(primitives):
         return [], []
-    order, nodes = build_bvh_arrays(triangles_array(primitives), split_method)
+    try:
+        order, nodes = build_bvh_arrays(triangles_array(primitives), split_method)
+    except (LtError, OSError):
+        # liblt_hip.so is linked against the HIP runtime: where it is not built or cannot load (a CPU-only host preparing
+        # a scene), the Python mirror above builds the same tree, node for node -- only slower.  Building a tree is host
+        # work; everything that computes on it still needs the library and fails loudly without it.
+        boxes = [BoundedBox(p, i) for i, p in enumerate(primitives)]
+        ordered = []
+        root, _, ordered, total = build_bvh(primitives, boxes, 0, len(primitives), ordered, 0, split_method)
+        linear = [LinearBVHNode() for _ in range(total)]
+        linear, _ = flatten_bvh(linear, root, 0)
+        return ordered, linear
     return [primitives[int(i)] for i in order], _LinearBVH(nodes)
 
 

@@ -163,6 +163,41 @@ def open_sheets(n=24, **kw):
     return Problem(media, (n, n, n), (-6.0, -6.0, -6.0), (12.0 / n,) * 3, mesh=mesh, source=src, **kw), ordered, linear
 
 
+def chain_mesh(T, seed=5):
+    """T small triangles strung along x under a flattened tree that is a CHAIN: every interior node splits one triangle off
+    (pre-order: interior i at 2i, its leaf at 2i + 1, the rest behind it) -- depth T - 1.  Returns (verts [T, 3, 3], nodes)."""
+    rs = np.random.RandomState(seed)
+    verts = np.zeros((T, 3, 3))
+    for k in range(T):
+        verts[k] = np.array([0.3 * k, 0.0, 0.0]) + rs.uniform(-0.12, 0.12, size=(3, 3))
+    lo, hi = verts.min(axis=1), verts.max(axis=1)
+    N = 2 * T - 1
+    nodes = dict(lo=np.zeros((N, 3)), hi=np.zeros((N, 3)), offset=np.zeros(N, np.int32), n_prims=np.zeros(N, np.int32),
+                 axis=np.zeros(N, np.int32))
+    for i in range(T - 1):
+        nodes["lo"][2 * i], nodes["hi"][2 * i] = lo[i:].min(axis=0), hi[i:].max(axis=0)
+        nodes["offset"][2 * i] = 2 * i + 2                                  # second child
+        nodes["lo"][2 * i + 1], nodes["hi"][2 * i + 1] = lo[i], hi[i]
+        nodes["offset"][2 * i + 1], nodes["n_prims"][2 * i + 1] = i, 1
+    nodes["lo"][N - 1], nodes["hi"][N - 1] = lo[T - 1], hi[T - 1]
+    nodes["offset"][N - 1], nodes["n_prims"][N - 1] = T - 1, 1
+    return verts, nodes
+
+
+def chain_rays(verts, n, seed=6):
+    """Rays aimed at (or just past) random points of random triangles of a chain_mesh, from origins around the chain: most
+    hit, many cross the boxes of several links, a quarter run nearly along the chain's axis (every level is entered)."""
+    rs = np.random.RandomState(seed)
+    T = len(verts)
+    o = rs.uniform(-1, 0.3 * T + 1, size=(n, 3)) * [1, 0, 0] + rs.uniform(-1, 1, size=(n, 3)) * [0, 1, 1]
+    o[: n // 4, 1:] *= 0.05
+    k = rs.randint(0, T, n)
+    bary = rs.dirichlet([1, 1, 1], n)
+    tgt = np.einsum("nk,nkc->nc", bary, verts[k]) + rs.normal(0, 0.03, size=(n, 3))
+    d = tgt - o
+    return o, d / np.linalg.norm(d, axis=1, keepdims=True), k
+
+
 def g8_inputs(g8, name):
     """Build the mesh (my BVH builder over the fixture's triangles) and tables of a G8 render."""
     from light_transport_amd.src.io import triangles_from_mesh

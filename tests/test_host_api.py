@@ -145,6 +145,25 @@ def _rand_tris(rs, n, spread=5.0, size=0.2):
             for c in rs.uniform(-spread, spread, size=(n, 3))]
 
 
+def test_build_linear_bvh_without_the_library(monkeypatch):
+    """A host where liblt_hip.so is not built / cannot load (it is linked against the HIP runtime) can still PREPARE a scene:
+    build_linear_bvh falls back to the Python builder, which gives the same tree node for node.  (Computing on it still
+    needs the library: there is no CPU fallback for that.)"""
+    from light_transport_amd import _lib
+    prims = cb.get_cornell_box(7.5, K.GLASS_MAT, K.GLASS_MAT, K.GLASS_MAT) + cb.get_cone(K.GLASS_MAT)
+    ordered, linear = B.build_linear_bvh(prims, 1)
+    want = B.linear_bvh_arrays(linear)
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/liblt_hip.so")
+    ordered2, linear2 = B.build_linear_bvh(prims, 1)
+    got = B.linear_bvh_arrays(linear2)
+    assert [id(p) for p in ordered2] == [id(p) for p in ordered] and len(linear2) == len(linear)
+    for k in ("lo", "hi", "offset", "n_prims"):
+        assert np.array_equal(got[k], want[k]), k
+    with pytest.raises(_lib.LtError):
+        _lib.lib()
+
+
 @pytest.mark.parametrize("split_method", [0, 1])
 def test_host_builder_equals_the_python_builder_node_for_node(split_method, golden_dir):
     """lt_build_bvh (C++, what build_linear_bvh uses) against build_bvh + flatten_bvh (the Python mirror of the reference's

@@ -249,6 +249,26 @@ def test_mcml_published_mismatched_semi_infinite():
     assert abs((c["w_escaped_top"] + c["w_specular"]) / n - 0.2600) < 0.003
 
 
+def test_oracle_traverses_trees_deeper_than_its_inline_stack():
+    """The library puts no limit on the depth of a flattened BVH (its device traversal is stackless; the GPU suite feeds it a
+    depth-59 chain), so the checker must not have one either: a depth-199 chain -- beyond the 64 entries the oracle's
+    traversal keeps inline -- gives the brute-force scan's hits, and a walk through it conserves energy."""
+    from tests import scenes as S
+    T = 200
+    verts, nodes = S.chain_mesh(T)
+    none = -np.ones(T, np.int32)
+    sc = O.OracleScene([(0.1, 1.0, 0.5, 1.0)], (8, 8, 8), (-1.0, -2.0, -2.0), (8.0, 0.5, 0.5),
+                       mesh=dict(verts=verts, med_front=none, med_back=none, nodes=nodes),
+                       source=dict(type=0, pos=(-0.5, 0.01, 0.02), dir=(1.0, 0.002, 0.001), extra=(0,) * 6, start_medium=0))
+    o, d, k = S.chain_rays(verts, 20000)
+    p1, t1 = sc.intersect_rays(o, d, None, True)
+    p0, t0 = sc.intersect_rays(o, d, None, False)
+    np.testing.assert_array_equal(p1, p0); np.testing.assert_array_equal(t1, t0)
+    assert (p0 >= 0).mean() > 0.4 and len(np.unique(p0[p0 >= 0])) == T
+    _, _, c = sc.run(2000, seed=1, threads=2, want_f64=False)       # rays along the chain's axis: every level is entered
+    assert abs(O.conservation_residual(c)) < 1e-9 * 2000 and c["w_escaped_mesh"] > 0
+
+
 def test_table_mode_equals_stream_semantics():
     """Table RNG addresses uniforms by (photon, step): permuting photons permutes nothing else."""
     prob = S.slab()
