@@ -348,6 +348,10 @@ int build_march_grid(lt_ctx* c)
         G.org[k] = c->nodes[0].lo[k] - G.h[k]; G.inv[k] = 1.0 / G.h[k];
     }
     G.nx = n[0]; G.ny = n[1]; G.nz = n[2];
+    for (int k = 0; k < 3; k++) {
+        G.fn[k] = (double)n[k]; G.fn32[k] = (float)n[k];
+        G.org32[k] = (float)G.org[k]; G.inv32[k] = (float)G.inv[k]; G.h32[k] = (float)G.h[k];
+    }
     const size_t cells = (size_t)n[0] * n[1] * n[2];
     // margin by which a cell is grown before the overlap test: far above the rounding of the f32 walk's positions and hit
     // parameters (1e-6 of the scene) and above the nudge by which the march steps past a cell wall, far below a cell
@@ -1163,6 +1167,8 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
         P.src_pos[k] = c->src_pos[k]; P.src_dir[k] = c->src_dir[k];
         P.src_e1[k] = c->src_extra[k]; P.src_e2[k] = c->src_extra[3 + k];
     }
+    P.fdim[0] = (double)c->nx; P.fdim[1] = (double)c->ny; P.fdim[2] = (double)c->nz;
+    for (int k = 0; k < 3; k++) { P.f32.origin[k] = (float)P.origin[k]; P.f32.inv_voxel[k] = (float)P.inv_voxel[k]; P.f32.fdim[k] = (float)P.fdim[k]; }
     P.src_type = c->src_type; P.start_medium = c->start_medium;
     P.table = (const double*)c->d_table.p; P.table_steps = table_steps;
     P.max_steps = c->max_steps;
@@ -1170,7 +1176,10 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     if (c->knob.query_min >= 1 && c->knob.query_min <= 64) P.query_min = (unsigned)c->knob.query_min;
     if (c->have_mesh && c->have_clear) {
         P.clear = (const uint4*)c->d_clear.p; P.cnx = c->cn[0]; P.cny = c->cn[1]; P.cnz = c->cn[2];
-        for (int k = 0; k < 3; k++) { P.corg[k] = c->corg[k]; P.cinv[k] = 1.0 / c->ccell[k]; }
+        for (int k = 0; k < 3; k++) {
+            P.corg[k] = c->corg[k]; P.cinv[k] = 1.0 / c->ccell[k]; P.cdim[k] = (double)c->cn[k];
+            P.f32.corg[k] = (float)P.corg[k]; P.f32.cinv[k] = (float)P.cinv[k]; P.f32.cdim[k] = (float)P.cdim[k];
+        }
     }
     if (c->have_mesh && c->have_march) P.mg = c->mgrid;
     c->captured_photons = 0;

@@ -85,6 +85,10 @@ struct MarchGrid {
     const uint32_t* list;
     int nx, ny, nz;
     double org[3], inv[3], h[3];   // origin, 1 / cell size, cell size
+    // the dimensions as reals and everything again in f32: a kernel reads its loop invariants in walk precision straight
+    // from its arguments (scalar registers) -- converted inside the kernel they are vector registers held through the hot loop
+    double fn[3];
+    float org32[3], inv32[3], h32[3], fn32[3];
     double nudge64, nudge32;       // by how much the f64 / f32 march steps past a cell wall (<< the margin of the lists)
 };
 
@@ -119,6 +123,11 @@ struct WalkParams {
     void* grid;
     int nx, ny, nz, tally;
     double origin[3], inv_voxel[3];
+    double fdim[3];       // (double)nx, ny, nz -- and below everything the hot loop compares positions with, again in f32: read in
+                          // walk precision from the kernel arguments these are scalar operands; an int -> real or f64 -> f32
+                          // conversion inside the kernel is hoisted in front of the loop and kept in a vector register
+    double cdim[3];       // clearance grid dimensions as reals
+    struct { float origin[3], inv_voxel[3], fdim[3], corg[3], cinv[3], cdim[3]; } f32;
     // source
     int src_type, start_medium;
     double src_pos[3], src_dir[3], src_e1[3], src_e2[3];

@@ -43,6 +43,10 @@ static_assert(sizeof(rocrand_state_xorwow) == 6 * sizeof(uint32_t), "rocrand_sta
 namespace ltk {
 
 #define LT_DEV __device__ __forceinline__
+// a loop invariant of the walk in walk precision R, read from the kernel arguments (WalkParams P / MarchGrid G): the f64
+// value or its f32 mirror -- a compile-time choice
+#define LT_PV(name, k) (sizeof(R) == 8 ? (R)P.name[k] : (R)P.f32.name[k])
+#define LT_GV(name, k) (sizeof(R) == 8 ? (R)G.name[k] : (R)G.name##32[k])
 
 // ---------------------------------------------------------------------------
 // precision traits
@@ -343,11 +347,41 @@ LT_DEV void nearest_listed(const TriD<R>* tris, const NodeD<R>* nodes, int n_nod
     }
 }
 
+// Can a hop of length s from o along d reach the PLANE of triangle T at all?  The hit parameter of tri_hit is, analytically,
+// t = ((a - o).n) / (d.n); the hop misses the triangle for certain when t <= 0 (the plane lies behind) or t >= s.  This is
+// a REJECTION test in front of tri_hit, never a replacement: it answers "no" only where tri_hit's own t -- computed another
+// way, so equal to this one up to rounding -- cannot lie inside (EPSILON, s): rays nearly parallel to the plane, where the
+// two parameters may differ by more than the margins, are always passed on.  On the Cornell cavity 89 % of the surface
+// queries find nothing -- a photon near a wall whose hop does not reach it -- and nearly all of those stop here.
+template <typename R> LT_DEV bool plane_within_reach(const TriD<R>* T, R px, R py, R pz, R ux, R uy, R uz, R s)
+{
+    const R nx = T->n[0], ny = T->n[1], nz = T->n[2];
+    const R ddn = ux * nx + uy * ny + uz * nz;
+    const R dist = (T->a[0] - px) * nx + (T->a[1] - py) * ny + (T->a[2] - pz) * nz;      // = t * ddn
+    const R addn = Mx<R>::abs(ddn);
+    const R graze = sizeof(R) == 8 ? (R)1e-3 : (R)1e-2, behind = sizeof(R) == 8 ? (R)1e-7 : (R)1e-2,
+            margin = sizeof(R) == 8 ? (R)(1.0 + 1e-4) : (R)(1.0 + 1e-2);
+    if (!(addn > graze)) return true;
+    const R tdd = ddn > 0 ? dist : -dist;       // t * |ddn|
+    return tdd >= -behind * addn && tdd <= s * addn * margin;
+}
+
+// The three decision uniforms a mesh walk holds while its step waits for a surface query: the f64 XORWOW walk keeps the raw
+// 32-bit draws (3 VGPRs instead of 6) and converts them when the step resumes -- the same conversion, the same value.
+template <typename R, bool TABLE> struct HeldU {
+    typedef R type;
+    static LT_DEV R get(R v) { return v; }
+};
+template <> struct HeldU<double, false> {
+    typedef unsigned type;
+    static LT_DEV double get(unsigned v) { return fma_kk((double)v, 2.3283064365386962891e-10); }     // Mx<double>::uniform32
+};
+
 // c0 of the cell that holds (px, py, pz): -1 outside the grid (always query)
 template <typename R> LT_DEV float march_clearance(const MarchGrid& G, R px, R py, R pz)
 {
-    const R cx = (px - (R)G.org[0]) * (R)G.inv[0], cy = (py - (R)G.org[1]) * (R)G.inv[1], cz = (pz - (R)G.org[2]) * (R)G.inv[2];
-    if (cx >= 0 && cx < (R)G.nx && cy >= 0 && cy < (R)G.ny && cz >= 0 && cz < (R)G.nz)
+    const R cx = (px - LT_GV(org, 0)) * LT_GV(inv, 0), cy = (py - LT_GV(org, 1)) * LT_GV(inv, 1), cz = (pz - LT_GV(org, 2)) * LT_GV(inv, 2);
+    if (cx >= 0 && cx < LT_GV(fn, 0) && cy >= 0 && cy < LT_GV(fn, 1) && cz >= 0 && cz < LT_GV(fn, 2))
         return __uint_as_float(G.cell[((size_t)(int)cz * G.ny + (int)cy) * G.nx + (int)cx].x & ~kMarchCountMask);
     return -1.0f;
 }
@@ -366,10 +400,10 @@ LT_DEV void nearest_march(const TriD<R>* tris, const NodeD<R>* nodes, int n_node
                           const R* d, R tmax, R t0, int& prim, R& t_out)
 {
     const R inf = Mx<R>::inf();
-    const R gx = (R)G.org[0], gy = (R)G.org[1], gz = (R)G.org[2];
-    const R ix_ = (R)G.inv[0], iy_ = (R)G.inv[1], iz_ = (R)G.inv[2];
-    const R hx = (R)G.h[0], hy = (R)G.h[1], hz = (R)G.h[2];
-    const R fnx = (R)G.nx, fny = (R)G.ny, fnz = (R)G.nz;
+    const R gx = LT_GV(org, 0), gy = LT_GV(org, 1), gz = LT_GV(org, 2);
+    const R ix_ = LT_GV(inv, 0), iy_ = LT_GV(inv, 1), iz_ = LT_GV(inv, 2);
+    const R hx = LT_GV(h, 0), hy = LT_GV(h, 1), hz = LT_GV(h, 2);
+    const R fnx = LT_GV(fn, 0), fny = LT_GV(fn, 1), fnz = LT_GV(fn, 2);
     const R tol = (R)1e-4;                       // in cells: positions this close outside the grid are clamped into it
     {
         const R fx = (o[0] - gx) * ix_, fy = (o[1] - gy) * iy_, fz = (o[2] - gz) * iz_;
@@ -469,8 +503,8 @@ LT_DEV bool march_enter(const MarchGrid& G, MarchWave<R>* W, R px, R py, R pz, R
     W->ray[7][lane] = Mx<R>::abs(uy) > tiny ? (R)1 / uy : inf;
     W->ray[8][lane] = Mx<R>::abs(uz) > tiny ? (R)1 / uz : inf;
     W->slot_t[lane] = march_bits(tmax); W->slot_i[lane] = kMarchNone;
-    const R fx = (px - (R)G.org[0]) * (R)G.inv[0], fy = (py - (R)G.org[1]) * (R)G.inv[1], fz = (pz - (R)G.org[2]) * (R)G.inv[2];
-    return fx >= -tol && fx <= (R)G.nx + tol && fy >= -tol && fy <= (R)G.ny + tol && fz >= -tol && fz <= (R)G.nz + tol;
+    const R fx = (px - LT_GV(org, 0)) * LT_GV(inv, 0), fy = (py - LT_GV(org, 1)) * LT_GV(inv, 1), fz = (pz - LT_GV(org, 2)) * LT_GV(inv, 2);
+    return fx >= -tol && fx <= LT_GV(fn, 0) + tol && fy >= -tol && fy <= LT_GV(fn, 1) + tol && fz >= -tol && fz <= LT_GV(fn, 2) + tol;
 }
 
 // One round: every marching lane visits the cell of its point at tcur, queues the cell's candidates and moves tcur on.
@@ -482,7 +516,7 @@ LT_DEV bool march_round(const MarchGrid& G, MarchWave<R>* W, bool& marching, boo
 {
     const unsigned lane = threadIdx.x & 63u;
     const R inf = Mx<R>::inf(), tol = (R)1e-4;
-    const R hx = (R)G.h[0], hy = (R)G.h[1], hz = (R)G.h[2];
+    const R hx = LT_GV(h, 0), hy = LT_GV(h, 1), hz = LT_GV(h, 2);
     const R nudge = sizeof(R) == 8 ? (R)G.nudge64 : (R)G.nudge32;
     unsigned n = 0, lst = 0;
     R tex = inf, bt = inf; float clr = 0.0f;
@@ -494,13 +528,13 @@ LT_DEV bool march_round(const MarchGrid& G, MarchWave<R>* W, bool& marching, boo
     if (m) {
         const R px = W->ray[0][lane], py = W->ray[1][lane], pz = W->ray[2][lane];
         const R ux = W->ray[3][lane], uy = W->ray[4][lane], uz = W->ray[5][lane];
-        const R fx = (px + tcur * ux - (R)G.org[0]) * (R)G.inv[0], fy = (py + tcur * uy - (R)G.org[1]) * (R)G.inv[1],
-                fz = (pz + tcur * uz - (R)G.org[2]) * (R)G.inv[2];
+        const R fx = (px + tcur * ux - LT_GV(org, 0)) * LT_GV(inv, 0), fy = (py + tcur * uy - LT_GV(org, 1)) * LT_GV(inv, 1),
+                fz = (pz + tcur * uz - LT_GV(org, 2)) * LT_GV(inv, 2);
         // out of the grid, or on its outer wall and heading out: nothing beyond the root bounds (the walls themselves are
         // listed in the outermost cells, which the march has visited by then)
-        if (!(fx >= -tol && fx <= (R)G.nx + tol && fy >= -tol && fy <= (R)G.ny + tol && fz >= -tol && fz <= (R)G.nz + tol) ||
-            (ux > 0 ? fx >= (R)G.nx : (ux < 0 && fx <= 0)) || (uy > 0 ? fy >= (R)G.ny : (uy < 0 && fy <= 0)) ||
-            (uz > 0 ? fz >= (R)G.nz : (uz < 0 && fz <= 0))) m = false;
+        if (!(fx >= -tol && fx <= LT_GV(fn, 0) + tol && fy >= -tol && fy <= LT_GV(fn, 1) + tol && fz >= -tol && fz <= LT_GV(fn, 2) + tol) ||
+            (ux > 0 ? fx >= LT_GV(fn, 0) : (ux < 0 && fx <= 0)) || (uy > 0 ? fy >= LT_GV(fn, 1) : (uy < 0 && fy <= 0)) ||
+            (uz > 0 ? fz >= LT_GV(fn, 2) : (uz < 0 && fz <= 0))) m = false;
         else {
             int cx = (int)__builtin_floor(fx), cy = (int)__builtin_floor(fy), cz = (int)__builtin_floor(fz);
             cx = cx < 0 ? 0 : (cx >= G.nx ? G.nx - 1 : cx);
@@ -512,9 +546,9 @@ LT_DEV bool march_round(const MarchGrid& G, MarchWave<R>* W, bool& marching, boo
             // parameter at which the ray leaves this cell (inf on an axis it does not move along: 1 / d is inf there and the
             // numerator is never 0 * inf because it is taken as inf outright)
             const R ix = W->ray[6][lane], iy = W->ray[7][lane], iz = W->ray[8][lane];
-            const R ex = ix < inf && ix > -inf ? ((R)G.org[0] + (R)(cx + (ux > 0 ? 1 : 0)) * hx - px) * ix : inf;
-            const R ey = iy < inf && iy > -inf ? ((R)G.org[1] + (R)(cy + (uy > 0 ? 1 : 0)) * hy - py) * iy : inf;
-            const R ez = iz < inf && iz > -inf ? ((R)G.org[2] + (R)(cz + (uz > 0 ? 1 : 0)) * hz - pz) * iz : inf;
+            const R ex = ix < inf && ix > -inf ? (LT_GV(org, 0) + (R)(cx + (ux > 0 ? 1 : 0)) * hx - px) * ix : inf;
+            const R ey = iy < inf && iy > -inf ? (LT_GV(org, 1) + (R)(cy + (uy > 0 ? 1 : 0)) * hy - py) * iy : inf;
+            const R ez = iz < inf && iz > -inf ? (LT_GV(org, 2) + (R)(cz + (uz > 0 ? 1 : 0)) * hz - pz) * iz : inf;
             tex = ex < ey ? (ex < ez ? ex : ez) : (ey < ez ? ey : ez);
         }
     }
@@ -668,6 +702,21 @@ template <typename R> LT_DEV void disk(R u0, R u1, R* d)
 }
 
 // cosine_weighted_hemisphere_sampling, S/utils.py:132-161
+// (cosine_hemi_frame: the same with the frame of n handed in -- the walk's source normal is the same for every photon, its
+// frame is made once per workgroup and kept in LDS instead of being carried through the hot loop in registers)
+template <typename R> LT_DEV void cosine_hemi_frame(const R* n, const R* v2, const R* v3, const R* wi_in, R u0, R u1, R* out)
+{
+    R wiz = -wi_in[2];  // :133
+    R d[2]; disk(u0, u1, d);
+    R zz = (R)1 - d[0] * d[0] - d[1] * d[1];
+    R z = Mx<R>::sqrt(zz > 0 ? zz : (R)0);  // :138
+    R oz = z;
+    if (wiz < 0) oz = -oz;  // :145-146
+    R pdf = (wiz * oz > 0) ? Mx<R>::abs(z) * (R)0.3183098861837907 : (R)0;  // :149-152
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[k] = d[0] * v2[k] + d[1] * v3[k] + oz * n[k];  // :154-157
+    out[3] = pdf;
+}
 template <typename R> LT_DEV void cosine_hemi(const R* n, const R* wi_in, R u0, R u1, R* out)
 {
     R wiz = -wi_in[2];  // :133
@@ -732,7 +781,7 @@ template <typename R> LT_DEV R boundary(const R* d, const R* nf, R n1, R n2, R* 
 // (ux, uy, -uz) -- v - 2 (v.n) n with n = (0, 0, +-1), no rounding at all; the refracted one is (Nr ux, Nr uy, sign(uz) cos_t),
 // of unit length by Snell's law (Nr^2 (1 - uz^2) + cos_t^2 = 1), so neither is renormalised.  n1 / n2 and Nr = n1 / n2 come
 // from the interface table (IfD).  Returns the unpolarised Fresnel reflectance; TIR (radicand <= 0, :110) returns 1.
-// oracle/lt_walk.inc: boundary_planar, the same operations with IEEE division and square root.
+// (The CPU checker restates the same operations with IEEE division and square root.)
 template <typename R> LT_DEV R boundary_planar(R uz, R n1, R n2, R Nr, R* cos_t_out)
 {
     const R cos_i = Mx<R>::abs(uz);
@@ -822,12 +871,13 @@ template <int TALLY> LT_DEV void tally_add(void* grid, unsigned idx, typename Ta
 LT_DEV size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 template <typename R> struct LdsLayout {
-    size_t off_cnt, off_media, off_zb, off_if, off_lm, off_tris, off_nodes, off_hist, off_march, total;
+    size_t off_cnt, off_frame, off_media, off_zb, off_if, off_lm, off_tris, off_nodes, off_hist, off_march, total;
     __host__ __device__ LdsLayout(int n_media, int n_layers, int n_tris, int n_nodes, unsigned n_hist = 0, size_t march_bytes = 0)
     {
         auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
         size_t o = 0;
         off_cnt = o;   o = al(o + 8 * sizeof(double));
+        off_frame = o; o = al(o + 6 * sizeof(R));      // frame of the source normal (area sources)
         off_media = o; o = al(o + (size_t)n_media * sizeof(MedD<R>));
         off_zb = o;    o = al(o + (size_t)(n_layers + 1) * sizeof(R));
         off_if = o;    o = al(o + (size_t)(n_layers > 0 ? n_layers + 1 : 0) * sizeof(IfD<R>));
@@ -912,8 +962,12 @@ LT_DEV void emit_deposit(const WalkParams& P, bool has, unsigned idx, typename T
     if (lg_chunk == kLogExhausted) {  // log exhausted: back to the linear voxel index and a global atomic
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(P.log_overflow, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (has) {
-            const unsigned tile = idx >> kTileShift, tx = tile % P.log_ntx, ty = (tile / P.log_ntx) % P.log_nty,
-                           tz = tile / (P.log_ntx * P.log_nty);
+            // (the divisors pass through an empty asm so that the reciprocal set-up of these divisions stays in this rare
+            // branch: left visible as loop invariants it was hoisted in front of the walk's loop and parked in registers)
+            unsigned ntx = P.log_ntx, nty = P.log_nty;
+            asm volatile("" : "+s"(ntx), "+s"(nty));
+            const unsigned tile = idx >> kTileShift, tx = tile % ntx, ty = (tile / ntx) % nty,
+                           tz = tile / (ntx * nty);
             const unsigned vx = (tx << kTileBX) | (idx & 31u), vy = (ty << kTileBY) | ((idx >> 5) & 31u),
                            vz = (tz << kTileBZ) | ((idx >> 10) & 15u);
             tally_add<TALLY>(P.grid, (vz * (unsigned)P.ny + vy) * (unsigned)P.nx + vx, val);
