@@ -58,21 +58,48 @@ namespace ltk {
 // the host libm in tests/test_gpu_parity.py through lt_eval) at 35 / 38 / 9 / 8 instructions.
 // a * b + k with the constant k in a scalar register pair: ONE v_fma_f64.  Left to itself the compiler parks
 // polynomial coefficients in VGPRs and spends a v_mov_b64 + v_fmac_f64 per Horner step (the VOP2 form accumulates
-// into its addend, and an f64 literal operand only carries the high dword).
-LT_DEV double fma_k(double a, double b, double k)
+// into its addend, and an f64 literal operand only carries the high dword; gfx9's VOP3 takes no literal at all).
+// The pair is written by two s_mov_b32 INSIDE the asm, into s[100:101], which the asm clobbers: handed in as an "s"
+// operand the ~40 constants of the walk's polynomials are loop invariants, all live through the hot loop at once
+// (80 SGPRs on top of the kernel's pointers and scalars), and the register allocator answered by spilling scalars into
+// VGPR lanes and restoring them with v_readlane -- VALU instructions -- every iteration (tens per photon-step once the
+// loop's other invariants had moved from VGPRs to kernel arguments).  Two scalar moves per use cost the VALU nothing.
+template <unsigned long long BITS> LT_DEV double fma_kb(double a, double b)
 {
     double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    asm("s_mov_b32 s100, %3\n\ts_mov_b32 s101, %4\n\tv_fma_f64 %0, %1, %2, s[100:101]"
+        : "=v"(r) : "v"(a), "v"(b), "i"((int)(unsigned)(BITS & 0xffffffffull)), "i"((int)(unsigned)(BITS >> 32)) : "s100", "s101");
     return r;
 }
+#define fma_k(a, b, k) fma_kb<__builtin_bit_cast(unsigned long long, (double)(k))>((a), (b))
+// a * k + c, the constant as the multiplier
+template <unsigned long long BITS> LT_DEV double fma_mkb(double a, double c)
+{
+    double r;
+    asm("s_mov_b32 s100, %3\n\ts_mov_b32 s101, %4\n\tv_fma_f64 %0, %1, s[100:101], %2"
+        : "=v"(r) : "v"(a), "v"(c), "i"((int)(unsigned)(BITS & 0xffffffffull)), "i"((int)(unsigned)(BITS >> 32)) : "s100", "s101");
+    return r;
+}
+#define fma_mk(a, k, c) fma_mkb<__builtin_bit_cast(unsigned long long, (double)(k))>((a), (c))
+// a * k
+template <unsigned long long BITS> LT_DEV double mul_kb(double a)
+{
+    double r;
+    asm("s_mov_b32 s100, %2\n\ts_mov_b32 s101, %3\n\tv_mul_f64 %0, %1, s[100:101]"
+        : "=v"(r) : "v"(a), "i"((int)(unsigned)(BITS & 0xffffffffull)), "i"((int)(unsigned)(BITS >> 32)) : "s100", "s101");
+    return r;
+}
+#define mul_k(a, k) mul_kb<__builtin_bit_cast(unsigned long long, (double)(k))>((a))
 // x * k + k, one v_fma_f64 with k read twice from the same scalar pair: the (0, 1] uniform conversions of
 // rocrand_uniform.h:97-109 (k = 2^-32 / 2^-53), which otherwise cost two v_mov_b32 to seed a v_fmac_f64
-LT_DEV double fma_kk(double x, double k)
+template <unsigned long long BITS> LT_DEV double fma_kkb(double x)
 {
     double r;
-    asm("v_fma_f64 %0, %1, %2, %2" : "=v"(r) : "v"(x), "s"(k));
+    asm("s_mov_b32 s100, %2\n\ts_mov_b32 s101, %3\n\tv_fma_f64 %0, %1, s[100:101], s[100:101]"
+        : "=v"(r) : "v"(x), "i"((int)(unsigned)(BITS & 0xffffffffull)), "i"((int)(unsigned)(BITS >> 32)) : "s100", "s101");
     return r;
 }
+#define fma_kk(x, k) fma_kkb<__builtin_bit_cast(unsigned long long, (double)(k))>((x))
 LT_DEV double fast_rcp(double d)
 {
     double r = __builtin_amdgcn_rcp(d);                 // v_rcp_f64: ~26 good bits
@@ -127,13 +154,13 @@ LT_DEV double neg_log_unit(double x)                     // -ln(x), x in [2^-53,
     const double lnm = __builtin_fma(2.0 * s * z, p, 2.0 * s);
     const double de = (double)e;
     // ln 2 split so that e * hi is exact for |e| <= 53
-    return -__builtin_fma(de, 6.93147180369123816490e-01, __builtin_fma(de, 1.90821492927058770002e-10, lnm));
+    return -fma_mk(de, 6.93147180369123816490e-01, fma_mk(de, 1.90821492927058770002e-10, lnm));
 }
 LT_DEV void sincos_turn_f64(double xi, double* sn, double* cs)  // sin, cos of 2*pi*xi, xi in (0, 1]
 {
     const double t = 4.0 * xi;                           // exact
     const double qf = __builtin_rint(t);
-    const double a = (t - qf) * 1.57079632679489661923;  // (t - qf) exact, |a| <= pi/4
+    const double a = mul_k(t - qf, 1.57079632679489661923);  // (t - qf) exact, |a| <= pi/4
     const double z = a * a;
     double ps = -7.6471637318198164759e-13;              // -1/15!
     ps = fma_k(ps, z, 1.6059043836821614599e-10);   //  1/13!
@@ -877,7 +904,7 @@ template <typename R> struct LdsLayout {
         auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
         size_t o = 0;
         off_cnt = o;   o = al(o + 8 * sizeof(double));
-        off_frame = o; o = al(o + 6 * sizeof(R));      // frame of the source normal (area sources)
+        off_frame = o; o = al(o + 15 * sizeof(R));     // frame of the source normal (area sources) + the grid's origin / inverse voxel / dimensions
         off_media = o; o = al(o + (size_t)n_media * sizeof(MedD<R>));
         off_zb = o;    o = al(o + (size_t)(n_layers + 1) * sizeof(R));
         off_if = o;    o = al(o + (size_t)(n_layers > 0 ? n_layers + 1 : 0) * sizeof(IfD<R>));
@@ -1032,21 +1059,44 @@ constexpr unsigned kMarchDrainMin = LT_MARCH_DRAIN_MIN;
 #ifndef LT_F32_WAVES
 #define LT_F32_WAVES 5
 #endif
+// where the walk keeps the grid's origin / inverse voxel size / dimensions (lt_walk_kernel.inc, LT_INV_MODE), chosen per kernel
+// from same-box A/B runs (profiles/r04c_ab_modes.log):
+//   slab kernels   1, pinned VGPRs: f64 127 VGPRs, the fewest VALU instructions (C2 walk 26.3 ms against 26.9 converted in
+//                  the kernel, 27.0 as scalar arguments, 27.2 from LDS) -- and the leaner builds (109-110 VGPRs) made the log
+//                  reduction beside a half-occupancy walk much slower (two lanes: 40.6-42.5 ms against 37.5-37.9)
+//   LDS-mesh       2, LDS: the Cornell kernel needs its 128 VGPRs for the photon and the held step; no scratch (60 B pinned),
+//                  C4 walk 28.4 ms against 31.7 pinned and 33.5 in round 3
+//   march kernel   0, scalar arguments: 156 VGPRs without scratch (from LDS it spills 36 B)
+#ifndef LT_INV_MODE_SLAB
+#define LT_INV_MODE_SLAB 1
+#endif
+#ifndef LT_INV_MODE_MESH
+#define LT_INV_MODE_MESH 2
+#endif
+#ifndef LT_INV_MODE_MARCH
+#define LT_INV_MODE_MARCH 0
+#endif
+#define LT_INV_MODE LT_INV_MODE_SLAB
 #define LT_WALK_NAME walk_kernel
 #define LT_WALK_BATCH 0
 #include "lt_walk_kernel.inc"
 #undef LT_WALK_NAME
 #undef LT_WALK_BATCH
+#undef LT_INV_MODE
+#define LT_INV_MODE LT_INV_MODE_MESH
 #define LT_WALK_NAME walk_kernel_q
 #define LT_WALK_BATCH 1
 #include "lt_walk_kernel.inc"
 #undef LT_WALK_NAME
 #undef LT_WALK_BATCH
+#undef LT_INV_MODE
+#define LT_INV_MODE LT_INV_MODE_MARCH
 #define LT_WALK_NAME walk_kernel_m
 #define LT_WALK_BATCH 2
 #include "lt_walk_kernel.inc"
 #undef LT_WALK_NAME
 #undef LT_WALK_BATCH
+#undef LT_INV_MODE
 
 // ---------------------------------------------------------------------------
 // variant dispatch

@@ -8,7 +8,7 @@ SRC=$ROOT/light_transport_amd/csrc
 OUT=$ROOT/gpurun_ab/$NAME
 mkdir -p $OUT
 make -s -C $SRC lt_api.o lt_bvh_build.o
-KF="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -munsafe-fp-atomics -Wall -Wno-unused-function $FLAGS"
+KF="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-inline-asm $FLAGS"
 ( cd $SRC && /opt/rocm/bin/hipcc $KF -c lt_kernels.hip -o $OUT/lt_kernels.o 2>&1 | grep -v "argument unused" || true ) &
 ( cd $SRC && /opt/rocm/bin/hipcc $KF -c lt_logtally.hip -o $OUT/lt_logtally.o 2>&1 | grep -v "argument unused" || true ) &
 wait
