@@ -25,6 +25,8 @@ Regimes (how a rank keeps its GPU busy; results are identical):
                 that one batch's log reduction runs beside the next batch's walk (lt_set_overlap 2)      [--inflight 1]
   two_jobs      TWO contexts take the steps in turn (two complete jobs in flight)                         [--inflight 2]
   three_jobs    THREE contexts (256^3 workloads: the logs of three jobs must fit)                         [--inflight 3]
+  walk_train    jobs in flight whose walks run one after another at 3/4 of the resident workgroups; the free quarter of
+                the register file carries the previous job's log reduction                               [--inflight 4]
   one_at_a_time ONE context, one lane: kernels strictly back to back                        [--inflight 1 --overlap 1]
 By default a short untimed probe runs all of them and the timed region uses the fastest; the probe's numbers are reported.
 
@@ -264,11 +266,25 @@ def measure_extra(name, make_ctx, args, cpu_seconds):
                 c = cs[j % 2]
                 c.sync(); steps += c.read_counters()["steps"]
             return (time.perf_counter() - t0) / k * 1e3, steps / k
+        # two ways of keeping two jobs in flight (bench.py's two_jobs and walk_train regimes at depth 2); the faster is reported,
+        # both are kept
         jobs(4, 700)                      # pilot batch of the scene, log sizing, warm-up
         ms, steps = jobs(8, 710)
+        regime, both = "two_jobs", {name + "_two_jobs_ms": ms}
+        if not args.f32_walk:
+            for c in cs:
+                c.set_tuning("serial_walks", 1); c.set_launch_config(3, 256)
+            jobs(4, 740)
+            ms_t, steps_t = jobs(8, 750)
+            both[name + "_walk_train_ms"] = ms_t
+            if ms_t < ms:
+                ms, steps, regime = ms_t, steps_t, "walk_train"
+            for c in cs:
+                c.set_tuning("serial_walks", -1)
         out = {name + "_ms": ms, name + "_steps_per_s": steps / (ms * 1e-3), name + "_photons_per_s": n / (ms * 1e-3),
-               name + "_frac": steps * BYTES_PER_STEP[args.tally] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, name + "_regime": "two_jobs",
+               name + "_frac": steps * BYTES_PER_STEP[args.tally] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, name + "_regime": regime,
                name + "_steps_per_job": steps}
+        out.update(both)
         cs.pop().close()
         c = cs[0]
         c.set_launch_config(0, 0); c.set_overlap(0)
@@ -322,8 +338,8 @@ def main(argv=None):
     ap.add_argument("--tally-mode", default="log", choices=["log", "atomic", "auto"],
                     help="log: deposit log + tile partition + LDS reduce (default); atomic: one global atomic per deposit")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="contexts taking the steps in turn: 2 / 3 = that many jobs in flight, 1 = one context; 0 (default) = an "
-                         "untimed probe picks the fastest regime")
+                    help="contexts taking the steps in turn: 2 / 3 = that many jobs in flight, 4 = the walk train (jobs in flight, walks "
+                         "one after another at 3/4 occupancy), 1 = one context; 0 (default) = an untimed probe picks the fastest regime")
     ap.add_argument("--overlap", type=int, default=-1,
                     help="lanes inside one launch (lt_set_overlap) for --inflight 1: 2 = one_call, 1 = one_at_a_time")
     ap.add_argument("--no-alone", action="store_true",
@@ -395,6 +411,12 @@ def main(argv=None):
     REGIMES = {"one_call": (1, 2), "two_jobs": (2, 1), "one_at_a_time": (1, 1)}
     if wl["grid"] <= 256:
         REGIMES["three_jobs"] = (3, 1)
+    # walk_train: jobs in flight whose WALKS run one after another (lt_set_tuning "serial_walks"), each at 3 of the 4 resident
+    # workgroups per CU (f32: 4 of 5) -- 92 % of a full walk's speed -- while the free quarter of every SIMD's register file
+    # carries the previous job's partition and tile reduce.  Two walks side by side at half occupancy each (two_jobs,
+    # three_jobs) fill the same registers but leave the reductions nothing until one of them ends.
+    if not args.f32_walk:
+        REGIMES["walk_train"] = (int(os.environ.get("LT_BENCH_TRAIN_DEPTH", 3 if wl["grid"] <= 256 else 2)), 1)
 
     def apply_regime(name):
         depth, lanes = REGIMES[name]
@@ -403,8 +425,12 @@ def main(argv=None):
         cs = pool[:depth]
         for c in cs:
             c.set_overlap(lanes)
-            # jobs in flight: each job's walk takes half of the resident workgroups (f64: 2 of 4 per CU; f32: 3 of 5)
-            c.set_launch_config(((3 if args.f32_walk else 2) if depth >= 2 else 0), 256 if depth >= 2 else 0)
+            if hasattr(c, "set_tuning"):
+                c.set_tuning("serial_walks", 1 if name == "walk_train" else -1)
+            # jobs in flight: each job's walk takes half of the resident workgroups (f64: 2 of 4 per CU; f32: 3 of 5);
+            # the walk train: three of four
+            train_bpc = int(os.environ.get("LT_BENCH_TRAIN_BPC", "3"))       # (measurement override)
+            c.set_launch_config((train_bpc if name == "walk_train" else (3 if args.f32_walk else 2)) if depth >= 2 else 0, 256 if depth >= 2 else 0)
             if args.tally_mode != "atomic":
                 c.reserve_log(per_gpu)    # scratch allocation is set-up, not part of a step (matters when --warmup 0)
         return cs
@@ -444,7 +470,9 @@ def main(argv=None):
         return (time.perf_counter() - t0) / n * 1e3
 
     probe = None
-    if args.inflight == 3:
+    if args.inflight == 4:
+        regime = "walk_train"
+    elif args.inflight == 3:
         regime = "three_jobs"
     elif args.inflight == 2:
         regime = "two_jobs"
@@ -456,7 +484,7 @@ def main(argv=None):
         # Untimed probe: which regime keeps THIS device busiest?  (Two streams only overlap when the runtime gives them
         # separate hardware queues -- see GPU_MAX_HW_QUEUES above -- so it is measured, not assumed.)
         probe = {}
-        for name in ("one_at_a_time", "one_call", "two_jobs", "three_jobs"):
+        for name in ("one_at_a_time", "one_call", "two_jobs", "three_jobs", "walk_train"):
             if name not in REGIMES:
                 continue
             cs = apply_regime(name)
@@ -737,7 +765,7 @@ def main(argv=None):
                 if cpu is not None and name + "_cpu_steps_per_s" in ex:
                     cpu[name + "_value"] = ex[name + "_cpu_steps_per_s"]
             rf["extras_note"] = ("cN_steps_per_s / cN_ms / cN_frac: whole jobs with two in flight (8 timed after 4 untimed, host clock "
-                                 "between syncs), frac = 16 B x photon-steps / ms / 8 TB/s; cN_one_launch_*: one lt_launch alone with the "
+                                 "between syncs; the faster of the two_jobs and walk_train regimes, cN_regime), frac = 16 B x photon-steps / ms / 8 TB/s; cN_one_launch_*: one lt_launch alone with the "
                                  "library's defaults (mean of 3, device time); cN_alone_*: that launch's kernels on one lane with nothing "
                                  "beside them; cN_cpu_steps_per_s: the CPU oracle on cN_cpu_cores threads, a ~3 s sample")
         print(json.dumps(out))

@@ -160,6 +160,12 @@ int lt_set_max_steps(lt_ctx* ctx, uint32_t max_steps);
  *   tail_split         slab walks in log mode: 0 = the whole walk in one kernel; default = split (a wave hands its last
  *                      photons to the tail kernel when at most 32 lanes are alive) where a drain is exposed and the batch
  *                      has >= 512 photons per launched wave; n >= 2 = split with threshold n (<= 48) whatever the size
+ *   part_alone         0 / 1: pin the partition build that shares the CU with a walk / the one for an otherwise idle device
+ *   serial_walks       1: WALK TRAIN -- the walk kernels of every context of this device that sets the knob run one after
+ *                      another (each waits for the end of the one enqueued before it; the log reductions stay on their own
+ *                      streams).  For hosts that keep several jobs in flight: launch each walk at three of the four resident
+ *                      workgroups per CU (lt_set_launch_config(3, 256)) and the free quarter of the register file carries the
+ *                      reduction of the job in front (bench.py's walk_train regime)
  *   -- taking effect when the mesh tables are next built (lt_set_mesh + launch / query):
  *   march_cells, march_scale_milli   march grid: cells along the longest axis / cell size in 1/1000 of the default
  *   clearance_cells    clearance grid of meshes in LDS: cells along the longest axis

@@ -140,7 +140,7 @@ struct lt_ctx {
     struct Knobs {
         long query_min = -1, log_bits2 = -1, log_hot = -1, overlap_walk_bpc = -1, diag_no_tally = -1, log_timing = -1,
              march_cells = -1, march_scale_milli = -1, no_march = -1, no_clearance = -1, no_near_lists = -1,
-             clearance_cells = -1, march_info = -1, force_march = -1, tail_split = -1, part_alone = -1;
+             clearance_cells = -1, march_info = -1, force_march = -1, tail_split = -1, part_alone = -1, serial_walks = -1;
         std::string overlap_pattern;      // LT_OVERLAP_PATTERN (relative sub-batch sizes; tools/pattern_ab.py)
     } knob;
     long* knob_by_name(const char* key)
@@ -150,7 +150,7 @@ struct lt_ctx {
             {"overlap_walk_bpc", &Knobs::overlap_walk_bpc}, {"diag_no_tally", &Knobs::diag_no_tally}, {"log_timing", &Knobs::log_timing},
             {"march_cells", &Knobs::march_cells}, {"march_scale_milli", &Knobs::march_scale_milli}, {"no_march", &Knobs::no_march},
             {"no_clearance", &Knobs::no_clearance}, {"no_near_lists", &Knobs::no_near_lists}, {"clearance_cells", &Knobs::clearance_cells},
-            {"march_info", &Knobs::march_info}, {"force_march", &Knobs::force_march}, {"tail_split", &Knobs::tail_split}, {"part_alone", &Knobs::part_alone}};
+            {"march_info", &Knobs::march_info}, {"force_march", &Knobs::force_march}, {"tail_split", &Knobs::tail_split}, {"part_alone", &Knobs::part_alone}, {"serial_walks", &Knobs::serial_walks}};
         for (const auto& t : tab) if (std::strcmp(key, t.k) == 0) return &(knob.*(t.m));
         return nullptr;
     }
@@ -695,6 +695,26 @@ struct LogRun {
     lt_ctx* c; WalkParams P; Variant v; LaunchCfg cfg; LogGeom G;
 };
 
+// Walk train (lt_set_tuning "serial_walks" = 1): the walk kernels of ALL contexts of a device that set the knob run one
+// after another -- each waits for the end of the one enqueued before it, whichever context that belongs to -- while every
+// context's log reduction stays on its own stream.  A host that keeps several jobs in flight then launches each walk at
+// THREE of the four resident workgroups per CU (lt_set_launch_config(3, 256): 92 % of the full walk's speed, measured
+// 30.6 against 28.2 ms on config 2) and the fourth slot -- 128 VGPRs per SIMD lane, enough for one partition or one
+// tile-reduce workgroup per CU -- carries the reduction of the job in front.  Two walks in flight at two workgroups each
+// (round 2-3's regimes) ran at the same total occupancy but left the reductions nothing until a walk had ended.
+// The gate is a ring of events that live as long as the process (a context may be destroyed while a later walk still waits).
+struct WalkGate {
+    std::mutex mu;
+    hipEvent_t ring[64] = {};
+    unsigned next = 0;
+    hipEvent_t last = nullptr;
+};
+WalkGate& walk_gate(int device)
+{
+    static WalkGate gates[16];
+    return gates[device & 15];
+}
+
 hipError_t lane_event(LogLane& ln, hipStream_t s)
 {
     if (ln.ev_used == ln.evs.size()) {
@@ -788,7 +808,8 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         const uint64_t waves_launched = (uint64_t)cfg.blocks * (uint64_t)(cfg.threads / 64);
         const bool big_enough = c->knob.tail_split >= 2 || bt.second >= kTailSplitMinPerWave * waves_launched;
         const bool split = R.v.mesh == 0 && !R.v.table && !R.v.capture && c->knob.tail_split != 0 && big_enough &&
-                           ((plan.lanes == 1 && c->blocks_per_cu == 0 && (!R.v.f32 || c->knob.tail_split >= 2)) || (plan.lanes > 1 && last_batch));
+                           ((plan.lanes == 1 && (c->blocks_per_cu == 0 || c->knob.serial_walks > 0) && (!R.v.f32 || c->knob.tail_split >= 2)) ||
+                            (plan.lanes > 1 && last_batch));
                            // (one lane, f32 walk: measured a LOSS -- 28.9 -> 31.6 ms on C2: the partition beside the tail kernel takes
                            //  3 ms longer and the f32 drain is short -- so it is left out there.)  (A host that runs walks at
                            // partial occupancy keeps several contexts in flight: their drains are hidden already, a tail kernel only adds contention)
@@ -811,9 +832,23 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
             P.pool = ln.pool.p; P.pool_n = (uint32_t*)ln.pool_n.p; P.pool_cap = (uint32_t)cap;
             vw.phase = 1;
         }
+        const bool train = c->knob.serial_walks > 0;
+        if (train) {
+            WalkGate& g = walk_gate(c->device);
+            std::lock_guard<std::mutex> lk(g.mu);
+            if (g.last) HIP_TRY(c, hipStreamWaitEvent(s, g.last, 0));
+        }
         HIP_TRY(c, lane_event(ln, s));
         HIP_TRY(c, launch_walk(P, vw, cfg, s));
         HIP_TRY(c, lane_event(ln, s));
+        if (train) {
+            WalkGate& g = walk_gate(c->device);
+            std::lock_guard<std::mutex> lk(g.mu);
+            hipEvent_t& ev = g.ring[g.next++ & 63u];
+            if (!ev) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIP_TRY(c, hipEventRecord(ev, s));
+            g.last = ev;
+        }
         if (split) {
             HIP_TRY(c, hipEventRecord(ln.ev_bulk, s));
             HIP_TRY(c, hipStreamWaitEvent(ln.tail_stream, ln.ev_bulk, 0));
@@ -898,7 +933,7 @@ int lt_create(lt_ctx** out, int device_id)
     c->device = device_id;
     {   // the one place the environment is read: LT_QUERY_MIN, LT_LOG_HOT, ... seed the knobs of lt_set_tuning
         static const char* const names[] = {"query_min", "log_bits2", "log_hot", "overlap_walk_bpc", "diag_no_tally", "log_timing", "march_cells",
-                                            "march_scale_milli", "no_march", "no_clearance", "no_near_lists", "clearance_cells", "march_info", "force_march", "tail_split", "part_alone"};
+                                            "march_scale_milli", "no_march", "no_clearance", "no_near_lists", "clearance_cells", "march_info", "force_march", "tail_split", "part_alone", "serial_walks"};
         for (const char* k : names) {
             std::string name = "LT_";
             for (const char* q = k; *q; q++) name += (char)std::toupper((unsigned char)*q);

@@ -64,6 +64,12 @@ namespace ltk {
 // (80 SGPRs on top of the kernel's pointers and scalars), and the register allocator answered by spilling scalars into
 // VGPR lanes and restoring them with v_readlane -- VALU instructions -- every iteration (tens per photon-step once the
 // loop's other invariants had moved from VGPRs to kernel arguments).  Two scalar moves per use cost the VALU nothing.
+#ifdef LT_K_IN_SGPR     /* A/B builds: the round-3 form, constants as "s" operands (loop invariants in scalar registers) */
+LT_DEV double fma_k(double a, double b, double k) { double r; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k)); return r; }
+LT_DEV double fma_mk(double a, double k, double c) { return __builtin_fma(a, k, c); }
+LT_DEV double mul_k(double a, double k) { return a * k; }
+LT_DEV double fma_kk(double x, double k) { double r; asm("v_fma_f64 %0, %1, %2, %2" : "=v"(r) : "v"(x), "s"(k)); return r; }
+#else
 template <unsigned long long BITS> LT_DEV double fma_kb(double a, double b)
 {
     double r;
@@ -100,6 +106,7 @@ template <unsigned long long BITS> LT_DEV double fma_kkb(double x)
     return r;
 }
 #define fma_kk(x, k) fma_kkb<__builtin_bit_cast(unsigned long long, (double)(k))>((x))
+#endif
 LT_DEV double fast_rcp(double d)
 {
     double r = __builtin_amdgcn_rcp(d);                 // v_rcp_f64: ~26 good bits

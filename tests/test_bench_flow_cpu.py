@@ -26,7 +26,8 @@ def run_bench(tmp_path, extra, nproc=2):
     return json.loads(lines[0]), calls
 
 
-@pytest.mark.parametrize("regime,flags", [("two_jobs", ["--inflight", "2"]), ("three_jobs", ["--inflight", "3"]), ("one_call", ["--inflight", "1"]),
+@pytest.mark.parametrize("regime,flags", [("two_jobs", ["--inflight", "2"]), ("three_jobs", ["--inflight", "3"]), ("walk_train", ["--inflight", "4"]),
+                                          ("one_call", ["--inflight", "1"]),
                                           ("one_at_a_time", ["--inflight", "1", "--overlap", "1"]), ("probe", [])])
 def test_bench_control_flow_world_size_2(tmp_path, regime, flags):
     K, W, n = 5, 2, 1000
@@ -37,7 +38,7 @@ def test_bench_control_flow_world_size_2(tmp_path, regime, flags):
     chosen = out["config"]["regime"]
     if regime == "probe":
         assert out["config"]["regime_probe"]["chosen"] == chosen
-        assert {"one_call_ms", "two_jobs_ms", "three_jobs_ms", "one_at_a_time_ms"} <= set(out["config"]["regime_probe"])
+        assert {"one_call_ms", "two_jobs_ms", "three_jobs_ms", "walk_train_ms", "one_at_a_time_ms"} <= set(out["config"]["regime_probe"])
     else:
         assert chosen == regime and out["config"]["regime_probe"] is None
     # value = photon-steps of ALL ranks (reduced to rank 0) / wall: the fake job reports 281 * n + seed steps per rank
@@ -67,13 +68,24 @@ def test_bench_control_flow_world_size_2(tmp_path, regime, flags):
                 assert state.get(c["ctx"]) == "flying"
             elif c["op"] == "sync":
                 state[c["ctx"]] = "idle"
-    depth = {"three_jobs": 3, "two_jobs": 2, "one_call": 1, "one_at_a_time": 1}[chosen]
+    depth = {"three_jobs": 3, "walk_train": 3, "two_jobs": 2, "one_call": 1, "one_at_a_time": 1}[chosen]
     assert out["config"]["jobs_in_flight"] == depth
     timed_ctx = {c["ctx"] for c in calls[0] if c["op"] == "launch" and c["seed"] < K}
     assert len(timed_ctx) == depth
     # rank 0's reference jobs: the split is switched off for the unoverlapped kernel times and restored afterwards
-    tun = [(c["key"], c["value"]) for c in calls[0] if c["op"] == "set_tuning"]
-    assert tun == [("tail_split", 0), ("tail_split", -1)] and not any(c["op"] == "set_tuning" for c in calls[1])
+    tun = [(c["key"], c["value"]) for c in calls[0] if c["op"] == "set_tuning" and c["key"] == "tail_split"]
+    assert tun == [("tail_split", 0), ("tail_split", -1)] and not any(c["op"] == "set_tuning" and c["key"] == "tail_split" for c in calls[1])
+    # the walk train: its contexts -- and only they, in the timed region -- serialise their walks and launch at 3 workgroups per CU
+    for cl in calls:
+        last = {}
+        for c in cl:
+            if c["op"] == "set_tuning" and c["key"] == "serial_walks":
+                last[c["ctx"]] = c["value"]
+            if c["op"] == "set_launch_config":
+                last[("bpc", c["ctx"])] = c["bpc"]
+            if c["op"] == "launch" and c["seed"] < K:
+                assert (last.get(c["ctx"], -1) == 1) == (chosen == "walk_train"), (chosen, c)
+                assert last.get(("bpc", c["ctx"])) == {"walk_train": 3, "three_jobs": 2, "two_jobs": 2}.get(chosen, 0), (chosen, c)
     # only rank 0 reads the grid back, after the timed region
     assert any(c["op"] == "read_grid_into" for c in calls[0]) and not any(c["op"] == "read_grid_into" for c in calls[1])
 
