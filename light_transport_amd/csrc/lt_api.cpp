@@ -807,7 +807,7 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         const bool last_batch = &bt == &plan.batches.back();
         const uint64_t waves_launched = (uint64_t)cfg.blocks * (uint64_t)(cfg.threads / 64);
         const bool big_enough = c->knob.tail_split >= 2 || bt.second >= kTailSplitMinPerWave * waves_launched;
-        const bool split = R.v.mesh == 0 && !R.v.table && !R.v.capture && c->knob.tail_split != 0 && big_enough &&
+        const bool split = R.v.mesh <= 1 && !R.v.table && !R.v.capture && c->knob.tail_split != 0 && big_enough &&
                            ((plan.lanes == 1 && (c->blocks_per_cu == 0 || c->knob.serial_walks > 0) && (!R.v.f32 || c->knob.tail_split >= 2)) ||
                             (plan.lanes > 1 && last_batch));
                            // (one lane, f32 walk: measured a LOSS -- 28.9 -> 31.6 ms on C2: the partition beside the tail kernel takes

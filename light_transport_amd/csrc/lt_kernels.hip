@@ -1167,10 +1167,26 @@ static WalkFn pick_phase(int tally)
     return nullptr;
 }
 
+// ... and the walk through a mesh in LDS (Variant::mesh 1)
+template <typename R, int PHASE>
+static WalkFn pick_phase_q(int tally)
+{
+    switch (tally) {
+    case LT_TALLY_F32: return walk_kernel_q<R, 1, false, LT_TALLY_F32, false, PHASE>;
+    case LT_TALLY_F64: return walk_kernel_q<R, 1, false, LT_TALLY_F64, false, PHASE>;
+    case LT_TALLY_U64FX: return walk_kernel_q<R, 1, false, LT_TALLY_U64FX, false, PHASE>;
+    }
+    return nullptr;
+}
+
 static WalkFn pick(const Variant& v)
 {
     if (v.phase) {
-        if (v.mesh || v.table || v.capture) return nullptr;
+        if (v.mesh > 1 || v.table || v.capture) return nullptr;
+        if (v.mesh == 1) {
+            if (v.phase == 1) return v.f32 ? pick_phase_q<float, 1>(v.tally) : pick_phase_q<double, 1>(v.tally);
+            return v.f32 ? pick_phase_q<float, 2>(v.tally) : pick_phase_q<double, 2>(v.tally);
+        }
         if (v.phase == 1) return v.f32 ? pick_phase<float, 1>(v.tally) : pick_phase<double, 1>(v.tally);
         return v.f32 ? pick_phase<float, 2>(v.tally) : pick_phase<double, 2>(v.tally);
     }
