@@ -112,6 +112,7 @@ struct lt_ctx {
     double rec_per_photon = 0.0;        // measured deposit records per photon (sizes the logs and the batches)
     int overlap_mode = 0;               // lt_set_overlap: 0 auto, 1 one lane, 2 two lanes
     double auto_ms_per_photon[kMaxLanes] = {0.0, 0.0, 0.0};   // overlap auto: device time per photon measured with 1 / 2 / 3 lanes
+    uint64_t auto_photons[kMaxLanes] = {0, 0, 0};             //               ... and the size of the launch it was measured on
     int auto_pending = -1;              // which of the two the launch in flight is measuring (-1: none)
     uint64_t captured_photons = 0;
     int blocks_per_cu = 0, threads_per_block = 0;
@@ -174,7 +175,7 @@ struct lt_ctx {
     }
     size_t grid_elem() const { return tally == LT_TALLY_F32 ? 4 : 8; }
     size_t n_vox() const { return (size_t)nx * (size_t)ny * (size_t)nz; }
-    void scene_changed() { rec_per_photon = 0.0; for (double& a : auto_ms_per_photon) a = 0.0; auto_pending = -1; dmap_valid = tile_cnt_ready = false; }
+    void scene_changed() { rec_per_photon = 0.0; for (double& a : auto_ms_per_photon) a = 0.0; for (uint64_t& a : auto_photons) a = 0; auto_pending = -1; dmap_valid = tile_cnt_ready = false; }
 };
 
 #define CHECK_CTX(c) do { if (!(c)) return LT_E_INVALID; } while (0)
@@ -507,7 +508,10 @@ int collect_log_stats(lt_ctx* c)
     if (c->auto_pending >= 0) {    // overlap auto: remember what this regime cost per photon
         float f = 0;
         if (hipEventElapsedTime(&f, c->ev0, c->ev1) == hipSuccess && c->pending_photons > 0)
+        {
             c->auto_ms_per_photon[c->auto_pending] = (double)f / (double)c->pending_photons;
+            c->auto_photons[c->auto_pending] = c->pending_photons;
+        }
         c->auto_pending = -1;
     }
     return LT_OK;
@@ -619,7 +623,10 @@ int plan_log(lt_ctx* c, uint64_t n, int lanes, LogPlan* plan)
     const double launched = 4.0 * (double)((b_target + 255) / 256);                          // 256-thread workgroups
     if (launched < waves) waves = launched;
     const double wave_slack = (double)kLogChunk * waves;
-    const double need = 1.25 * rate * (double)b_target + wave_slack + 1048576.0;
+    // (walk workgroup b claims chunks of group b % 16 only: a launch of fewer than 16 workgroups -- under 4096 photons -- reaches
+    // 1/16 of the log per workgroup it has, so the log is sized for the groups in use)
+    const double groups_used = launched / 4.0 < (double)kLogGroups ? (launched / 4.0 < 1.0 ? 1.0 : launched / 4.0) : (double)kLogGroups;
+    const double need = (1.25 * rate * (double)b_target + 1048576.0) * ((double)kLogGroups / groups_used) + wave_slack;
     size_t want = need < (double)per_lane ? (size_t)need : per_lane;
     want = ((want + kLogChunk - 1) / kLogChunk) * kLogChunk;
     size_t cap_use = per_lane;
@@ -684,8 +691,13 @@ int choose_lanes(lt_ctx* c, uint64_t n)
     if (c->overlap_mode == 1) return 1;
     if (c->overlap_mode >= 2) return n >= 8192 ? c->overlap_mode : 1;
     if (c->blocks_per_cu > 0 || n < kOverlapMinPhotons) return 1;    // the caller pinned the launch geometry / small job
-    for (int k = kAutoLanes - 1; k >= 0; k--)
-        if (c->auto_ms_per_photon[k] <= 0.0) { c->auto_pending = k; return k + 1; }
+    // A regime's cost per photon is only comparable between launches of similar size (a launch's fixed costs -- pipeline fill,
+    // the drain of its longest photons -- weigh more on a small one): a measurement taken on a launch more than 2x away from
+    // this one's size is measured again.
+    for (int k = kAutoLanes - 1; k >= 0; k--) {
+        const bool stale = c->auto_photons[k] != 0 && (n > 2 * c->auto_photons[k] || c->auto_photons[k] > 2 * n);
+        if (c->auto_ms_per_photon[k] <= 0.0 || stale) { c->auto_pending = k; return k + 1; }
+    }
     int best = 0;
     for (int k = 1; k < kAutoLanes; k++) if (c->auto_ms_per_photon[k] < c->auto_ms_per_photon[best]) best = k;
     return best + 1;
@@ -1378,6 +1390,7 @@ int lt_set_overlap(lt_ctx* c, int lanes)
     if (lanes < 0 || lanes > kMaxLanes) return c->fail(LT_E_INVALID, "lt_set_overlap: 0 (auto), 1, 2 or 3");
     c->overlap_mode = lanes;
     for (double& a : c->auto_ms_per_photon) a = 0.0;
+    for (uint64_t& a : c->auto_photons) a = 0;
     c->auto_pending = -1;
     return LT_OK;
 }
