@@ -1073,7 +1073,9 @@ constexpr unsigned kMarchDrainMin = LT_MARCH_DRAIN_MIN;
 //                  reduction beside a half-occupancy walk much slower (two lanes: 40.6-42.5 ms against 37.5-37.9)
 //   LDS-mesh       2, LDS: the Cornell kernel needs its 128 VGPRs for the photon and the held step; no scratch (60 B pinned),
 //                  C4 walk 28.4 ms against 31.7 pinned and 33.5 in round 3
-//   march kernel   0, scalar arguments: 156 VGPRs without scratch (from LDS it spills 36 B)
+//   march kernel   2, LDS: teapot / cow / pumpkin 19.0 / 18.9 / 17.8e9 f64 steps/s against 17.8 / 17.6 / 16.9 as scalar arguments
+//                  (156 VGPRs without scratch, but the scalar file overflows into v_readlane restores) and 18.1 / 18.0 / 17.1
+//                  pinned (profiles/r04d_march_modes.log); 154 VGPRs + 36 B of scratch
 #ifndef LT_INV_MODE_SLAB
 #define LT_INV_MODE_SLAB 1
 #endif
@@ -1081,7 +1083,7 @@ constexpr unsigned kMarchDrainMin = LT_MARCH_DRAIN_MIN;
 #define LT_INV_MODE_MESH 2
 #endif
 #ifndef LT_INV_MODE_MARCH
-#define LT_INV_MODE_MARCH 0
+#define LT_INV_MODE_MARCH 2
 #endif
 #define LT_INV_MODE LT_INV_MODE_SLAB
 #define LT_WALK_NAME walk_kernel

@@ -11,7 +11,7 @@ g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 ctx = lt.Context(0)
 for name in ("teapot", "cow", "pumpkin"):
     prob = S.obj_in_box(g[name + "_verts"], g[name + "_faces"])[0]
-    for dtype, f32 in (("f64", False), ("f32", True)):
+    for dtype, f32 in ((("f64", False),) if os.environ.get("OBJ_F64_ONLY") else (("f64", False), ("f32", True))):
         prob.apply(ctx, dtype); ctx.set_tally_mode("log"); ctx.set_overlap(1)
         best = 1e9
         for r in range(3):
