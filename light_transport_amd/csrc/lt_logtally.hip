@@ -229,7 +229,6 @@ __global__ void __launch_bounds__(kPartThreads, ALONE ? LT_PART_WAVES_ALONE : LT
     const uint16_t* s_dmap = reinterpret_cast<const uint16_t*>(s_b + kMaxBins);   // [n_tiles], HOT only
     __shared__ uint32_t s_wsum[kPartThreads / 64];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nb1 = L.bits2 ? (L.n_tiles + (1u << L.bits2) - 1) >> L.bits2 : L.n_tiles;
     const uint32_t mask2 = (1u << L.bits2) - 1;
     const uint32_t H = L.dmap ? L.dmeta[0] : 0u;          // hot tiles: pass-1 digits 0 .. H-1, final after pass 1
@@ -256,23 +255,23 @@ __global__ void __launch_bounds__(kPartThreads, ALONE ? LT_PART_WAVES_ALONE : LT
         if (PASS == 1) return make_uint4(u * kLogChunk, L.log_fill[u], 0u, 0u);
         return reinterpret_cast<const uint4*>(L.itab)[u];
     };
-    uint32_t key[kPerThread], ret[kPerThread];
+    uint32_t key[kPerThread], ret2[kPerThread / 2];      // ranks inside the digit (< 4096): two per register
     TV val[kPerThread];
     // lane owns records k = g * 2048 + tid * 4 + j: 16 B of indices and 16 / 32 B of values per load group.  Groups are
     // read whole and unconditionally: the bytes behind an item's end are mapped (slack behind every buffer), and
     // records at k >= n are masked out below.  Indices are requested an item ahead; values only after the ranking (they
     // are first needed at the LDS scatter), which keeps the kernel within 64 VGPRs: four waves per SIMD beside a walk.
-    auto load_keys = [&](uint32_t lo_) {
+    auto load_keys = [&](uint32_t lo_, uint32_t tid_) {
 #pragma unroll
         for (int g = 0; g < kPerThread / 4; g++) {
-            const uint4 q = *reinterpret_cast<const uint4*>(in_idx + lo_ + (uint32_t)g * (kPartThreads * 4) + threadIdx.x * 4);
+            const uint4 q = *reinterpret_cast<const uint4*>(in_idx + lo_ + (uint32_t)g * (kPartThreads * 4) + tid_ * 4);
             key[4 * g] = q.x; key[4 * g + 1] = q.y; key[4 * g + 2] = q.z; key[4 * g + 3] = q.w;
         }
     };
-    auto load_vals = [&](uint32_t lo_) {
+    auto load_vals = [&](uint32_t lo_, uint32_t tid_) {
 #pragma unroll
         for (int g = 0; g < kPerThread / 4; g++) {
-            const Quad<TV> v = *reinterpret_cast<const Quad<TV>*>(in_val + lo_ + (uint32_t)g * (kPartThreads * 4) + threadIdx.x * 4);
+            const Quad<TV> v = *reinterpret_cast<const Quad<TV>*>(in_val + lo_ + (uint32_t)g * (kPartThreads * 4) + tid_ * 4);
 #pragma unroll
             for (int j = 0; j < 4; j++) val[4 * g + j] = v.v[j];
         }
@@ -282,8 +281,15 @@ __global__ void __launch_bounds__(kPartThreads, ALONE ? LT_PART_WAVES_ALONE : LT
     if (unit >= n_units) return;
     uint4 ds = describe(unit);
     uint4 dsn = unit + gridDim.x < n_units ? describe(unit + gridDim.x) : make_uint4(0u, 0u, 0u, 0u);
-    load_keys(ds.x);
+    load_keys(ds.x, threadIdx.x);
   for (;;) {
+    // The lane's id passes through an empty asm once per item: everything derived from it (its slice of the item, LDS and
+    // global addresses, the scan's lane masks) is then recomputed per item -- a handful of integer instructions against 4096
+    // records -- instead of being hoisted in front of the loop as loop invariants, where the 64-VGPR build had to spill them
+    // (28 B of scratch per lane and a dozen wave masks parked in VGPR lanes).
+    uint32_t tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = (int)(tid & 63u), wave = (int)(tid >> 6);
     // this item: records [ds.x + sub * 4096, ...) of the unit; the one after it
     const uint32_t off = sub * kPartItem;
     const uint32_t n = ds.y > off ? (ds.y - off < kPartItem ? ds.y - off : kPartItem) : 0;
@@ -295,23 +301,24 @@ __global__ void __launch_bounds__(kPartThreads, ALONE ? LT_PART_WAVES_ALONE : LT
     if (PASS == 1) { cursor = L.cursor1 + (unit & (kLogGroups - 1)); cstride = kLogGroups; }        // the cursors of the chunk's group
     else { cursor = L.cursor2 + ((size_t)((ds.z - H) << L.bits2) * kLogGroups2 + (unit & (kLogGroups2 - 1))); cstride = kLogGroups2; }
     if (n != 0) {
-    for (uint32_t d = threadIdx.x; d < nb + 2; d += kPartThreads) s_a[d] = 0;
+    for (uint32_t d = tid; d < nb + 2; d += kPartThreads) s_a[d] = 0;
     __syncthreads();
     // ---- rank inside the digit: one returning LDS atomic per record.  (Counting the lanes that share the first
     //      lane's digit with a ballot and adding once for all of them removes the same-address serialisation of the
     //      hot digits but costs ~150 instructions per record slot: measured slower, alone and beside a walk.)
 #pragma unroll
     for (int r = 0; r < kPerThread; r++) {
-        const uint32_t k = (uint32_t)(r >> 2) * (kPartThreads * 4) + threadIdx.x * 4 + (r & 3);
-        ret[r] = k < n ? atomicAdd(&s_a[digit(key[r])], 1u) : 0u;
+        const uint32_t k = (uint32_t)(r >> 2) * (kPartThreads * 4) + tid * 4 + (r & 3);
+        const uint32_t rk = k < n ? atomicAdd(&s_a[digit(key[r])], 1u) : 0u;
+        if (r & 1) ret2[r >> 1] |= rk << 16; else ret2[r >> 1] = rk;
     }
-    load_vals(ds.x + off);     // in flight during the scan
+    load_vals(ds.x + off, tid);     // in flight during the scan
     __syncthreads();
     // ---- space for every non-empty digit: one returning global atomic each, issued before the scan so that its
     //      latency runs under the scan and the LDS scatter
     uint32_t c0 = 0, c1 = 0, g0 = 0, g1 = 0, incl;
     {
-        const uint32_t d = 2 * threadIdx.x;
+        const uint32_t d = 2 * tid;
         if (d < nb) { const uint2 cc = *reinterpret_cast<const uint2*>(&s_a[d]); c0 = cc.x; c1 = d + 1 < nb ? cc.y : 0; }
         if (c0) g0 = atomicAdd(&cursor[d * cstride], c0);
         if (c1) g1 = atomicAdd(&cursor[(d + 1) * cstride], c1);
@@ -328,23 +335,23 @@ __global__ void __launch_bounds__(kPartThreads, ALONE ? LT_PART_WAVES_ALONE : LT
 #pragma unroll
         for (int w = 0; w < kPartThreads / 64; w++) before += w < wave ? s_wsum[w] : 0;
         ex = before + incl - (c0 + c1);
-        const uint32_t d = 2 * threadIdx.x;
+        const uint32_t d = 2 * tid;
         if (d < nb) *reinterpret_cast<uint2*>(&s_a[d]) = make_uint2(ex, ex + c0);
     }
     __syncthreads();
     // ---- digit-sorted copy in LDS
 #pragma unroll
     for (int r = 0; r < kPerThread; r++) {
-        const uint32_t k = (uint32_t)(r >> 2) * (kPartThreads * 4) + threadIdx.x * 4 + (r & 3);
+        const uint32_t k = (uint32_t)(r >> 2) * (kPartThreads * 4) + tid * 4 + (r & 3);
         if (k < n) {
-            const uint32_t p = s_a[digit(key[r])] + ret[r];
+            const uint32_t p = s_a[digit(key[r])] + ((r & 1) ? ret2[r >> 1] >> 16 : (ret2[r >> 1] & 0xffffu));
             s_key[p] = key[r]; s_val[p] = val[r];
         }
     }
     // ---- the registers are free: request the next item now, it arrives during the write-out
-    if (have_next) load_keys(next_lo);
+    if (have_next) load_keys(next_lo, tid);
     {
-        const uint32_t d = 2 * threadIdx.x;
+        const uint32_t d = 2 * tid;
         if (c0) s_b[d] = g0 - ex;
         if (c1) s_b[d + 1] = g1 - (ex + c0);
     }
@@ -352,7 +359,7 @@ __global__ void __launch_bounds__(kPartThreads, ALONE ? LT_PART_WAVES_ALONE : LT
     // ---- write out: consecutive sorted positions of one digit are consecutive in memory
 #pragma unroll
     for (int i = 0; i < kPerThread; i++) {
-        const uint32_t p = threadIdx.x + (uint32_t)i * kPartThreads;
+        const uint32_t p = tid + (uint32_t)i * kPartThreads;
         if (p < n) {
             const uint32_t kk = s_key[p];
             const uint32_t dg = digit(kk);
@@ -370,7 +377,7 @@ __global__ void __launch_bounds__(kPartThreads, ALONE ? LT_PART_WAVES_ALONE : LT
         }
     }
     __syncthreads();   // LDS is reused by the next item
-    } else if (have_next) load_keys(next_lo);     // an empty item (a chunk nobody claimed, a short last chunk)
+    } else if (have_next) load_keys(next_lo, tid);     // an empty item (a chunk nobody claimed, a short last chunk)
     if (!have_next) break;
     if (more_here) sub++;
     else {
