@@ -266,7 +266,9 @@ int lt_reduce_grid(lt_ctx* ctx, void* nccl_comm, int root);
  * EPSILON < t < tmax.  prim_out = -1, t_out = +inf when nothing is hit.
  * use_bvh = 0: brute force over all triangles; 1: the flattened BVH; 2: the march grid as the walk uses it for meshes beyond
  * LDS (wave-cooperative: lanes march their rays through the grid, the whole wave tests the candidates; built on request for
- * smaller meshes); 3: the same march lane by lane.  All four give the same answer bit for bit. */
+ * smaller meshes); 3: the same march lane by lane; 4: the BVH front to back -- the child on the ray's side of the split plane
+ * first, the reference's order (bvh_new.py:455-458), threaded per direction sign pattern so that it needs no stack: what the
+ * surface renderers use.  All five give the same answer bit for bit. */
 int lt_intersect_rays(lt_ctx* ctx, const double* origins, const double* dirs,
                       const double* tmax, size_t n, int use_bvh, int32_t* prim_out,
                       double* t_out);

@@ -125,7 +125,7 @@ struct lt_ctx {
     double corg[3] = {0, 0, 0}, ccell[3] = {1, 1, 1};
     bool have_clear = false;
     // march grid (meshes whose f64 tables exceed the LDS budget): cell records, candidate lists, scratch of the builder
-    DevBuf d_mcell, d_mlist, d_mcoarse;
+    DevBuf d_mcell, d_mlist, d_mcoarse, d_links;      // d_links: front-to-back threading of the BVH (bvh_octant_links)
     MarchGrid mgrid;
     bool have_march = false;
     size_t march_entries = 0;
@@ -995,7 +995,7 @@ int lt_destroy(lt_ctx* c)
     c->d_mats.release(); c->d_lights.release(); c->d_r0.release(); c->d_r1.release(); c->d_lc.release();
     c->d_img.release(); c->d_xy.release(); c->d_vtx.release(); c->d_vcnt.release(); c->d_clear.release();
     c->d_job.release(); c->d_dmap.release(); c->d_dmeta.release();
-    c->d_mcell.release(); c->d_mlist.release(); c->d_mcoarse.release();
+    c->d_mcell.release(); c->d_mlist.release(); c->d_mcoarse.release(); c->d_links.release();
     for (int k = 1; k < kMaxLanes; k++) { c->d_gridx[k - 1].release(); if (c->lanes[k].stream) (void)hipStreamSynchronize(c->lanes[k].stream); }
     for (int k = 0; k < kMaxLanes; k++) {
         c->lanes[k].release_all();
@@ -1576,6 +1576,18 @@ int stage_in(lt_ctx* c, DevBuf& b, const void* h, size_t bytes)
 }
 }  // namespace
 
+static bool bvh_octant_links(const std::vector<lt_bvh_node>& nd, std::vector<int16_t>& out);
+// the link tables of the ctx mesh on the device (rebuilt per call: a few KB; the mesh may have changed)
+static int upload_links(lt_ctx* c)
+{
+    std::vector<int16_t> links;
+    if (!bvh_octant_links(c->nodes, links)) return c->fail(LT_E_UNSUPPORTED, "BVH of %zu nodes: the front-to-back order tables hold 16-bit links", c->nodes.size());
+    HIP_TRY(c, c->d_links.ensure(links.size() * sizeof(int16_t) + 4));
+    HIP_TRY(c, hipMemcpyAsync(c->d_links.p, links.data(), links.size() * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // (the staging vector dies here)
+    return LT_OK;
+}
+
 int lt_intersect_rays(lt_ctx* c, const double* origins, const double* dirs, const double* tmax, size_t n, int use_bvh,
                       int32_t* prim_out, double* t_out)
 {
@@ -1583,12 +1595,13 @@ int lt_intersect_rays(lt_ctx* c, const double* origins, const double* dirs, cons
     if (!c->have_mesh) return c->fail(LT_E_STATE, "lt_intersect_rays: lt_set_mesh first");
     if (n == 0) return LT_OK;
     if (!origins || !dirs || !prim_out || !t_out) return c->fail(LT_E_INVALID, "lt_intersect_rays: null argument");
-    if (use_bvh < 0 || use_bvh > 3) return c->fail(LT_E_INVALID, "lt_intersect_rays: use_bvh must be 0 (brute force), 1 (BVH), 2 (march grid, wave-cooperative) or 3 (march grid, lane by lane)");
+    if (use_bvh < 0 || use_bvh > 4) return c->fail(LT_E_INVALID, "lt_intersect_rays: use_bvh must be 0 (brute force), 1 (BVH), 2 (march grid, wave-cooperative), 3 (march grid, lane by lane) or 4 (BVH, front to back)");
     BIND(c);
     if (c->media.empty()) { lt_medium m = {0, 0, 0, 1}; c->media.push_back(m); }
     int rc = upload_tables(c);
     if (rc) return rc;
-    if (use_bvh >= 2 && !c->have_march) {      // small meshes have no march grid of their own: build one on request
+    if (use_bvh == 4 && (rc = upload_links(c))) return rc;
+    if ((use_bvh == 2 || use_bvh == 3) && !c->have_march) {      // small meshes have no march grid of their own: build one on request
         if ((rc = build_march_grid(c))) return rc;
         if (!c->have_march) return c->fail(LT_E_UNSUPPORTED, "lt_intersect_rays: no march grid for this mesh");
     }
@@ -1604,7 +1617,7 @@ int lt_intersect_rays(lt_ctx* c, const double* origins, const double* dirs, cons
     HIP_TRY(c, launch_intersect_rays(c->d_tris[0].p, c->d_nodes[0].p, (int)c->med_front.size(), (int)c->nodes.size(),
                                      (const double*)base, (const double*)(base + vb),
                                      tmax ? (const double*)(base + 2 * vb) : nullptr, n, use_bvh, c->have_march ? &c->mgrid : nullptr,
-                                     (int32_t*)c->d_scratch_aux.p, (double*)c->d_scratch_out.p, c->stream));
+                                     use_bvh == 4 ? (const int16_t*)c->d_links.p : nullptr, (int32_t*)c->d_scratch_aux.p, (double*)c->d_scratch_out.p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(prim_out, c->d_scratch_aux.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(t_out, c->d_scratch_out.p, tb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1727,6 +1740,32 @@ int lt_set_lights(lt_ctx* c, const lt_point_light* lights, int n)
     return LT_OK;
 }
 
+// Front-to-back threading of a flattened pre-order BVH for each of the 8 sign patterns of a ray direction (bit k set: the
+// direction is negative on axis k): first[i] = the child of interior node i that lies on the ray's side of the split plane --
+// the second child if the direction is negative on the node's axis, else the first (S/bvh_new.py:455-458) -- and after[i] = the
+// node the search goes to once the subtree of i is done (n = finished).  Layout [pattern][first | after][node], int16.
+static bool bvh_octant_links(const std::vector<lt_bvh_node>& nd, std::vector<int16_t>& out)
+{
+    const int n = (int)nd.size();
+    if (n <= 0 || n > 32767) return false;
+    out.assign((size_t)16 * n, (int16_t)n);
+    for (int oct = 0; oct < 8; oct++) {
+        int16_t* first = &out[(size_t)oct * 2 * n]; int16_t* after = first + n;
+        std::vector<std::pair<int, int>> todo{{0, n}};     // (node, where to go after its subtree)
+        while (!todo.empty()) {
+            const auto [i, a] = todo.back(); todo.pop_back();
+            after[i] = (int16_t)a;
+            if (nd[(size_t)i].n_prims > 0) continue;
+            const int c0 = i + 1, c1 = nd[(size_t)i].offset;
+            const bool neg = (oct >> nd[(size_t)i].axis) & 1;
+            const int near_ = neg ? c1 : c0, far_ = neg ? c0 : c1;
+            first[i] = (int16_t)near_;
+            todo.emplace_back(near_, far_); todo.emplace_back(far_, a);
+        }
+    }
+    return true;
+}
+
 static int render_impl(lt_ctx* c, int variant, int choices, int width, int height, int samples, int max_depth,
                        const double camera[3], double f_distance, const double* xs, const double* ys, double* rand_0,
                        const double* rand_1, const int32_t* light_choice, double* image)
@@ -1754,6 +1793,7 @@ static int render_impl(lt_ctx* c, int variant, int choices, int width, int heigh
     HIP_TRY(c, c->d_lights.ensure(c->lights.size() * sizeof(lt_point_light)));
     HIP_TRY(c, c->d_r0.ensure(n_tab * 8)); HIP_TRY(c, c->d_r1.ensure(n_tab * 8)); HIP_TRY(c, c->d_lc.ensure(n_lc * 4));
     HIP_TRY(c, c->d_img.ensure(n_img * 8)); HIP_TRY(c, c->d_xy.ensure((size_t)(width + height) * 8));
+    if ((rc = upload_links(c))) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->d_mats.p, c->surf_mats.data(), c->surf_mats.size() * sizeof(lt_surface_material), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_lights.p, c->lights.data(), c->lights.size() * sizeof(lt_point_light), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_r0.p, rand_0, n_tab * 8, hipMemcpyHostToDevice, c->stream));
@@ -1766,6 +1806,7 @@ static int render_impl(lt_ctx* c, int variant, int choices, int width, int heigh
     std::memset(&P, 0, sizeof P);
     P.tris = c->d_tris[0].p; P.nodes = c->d_nodes[0].p;
     P.mats = (const lt_surface_material*)c->d_mats.p; P.lights = (const lt_point_light*)c->d_lights.p;
+    P.links = (const int16_t*)c->d_links.p;
     P.n_tris = (int)c->med_front.size(); P.n_nodes = (int)c->nodes.size(); P.n_lights = (int)c->lights.size();
     P.W = width; P.H = height; P.S = samples; P.D = max_depth;
     for (int k = 0; k < 3; k++) P.cam[k] = camera[k];

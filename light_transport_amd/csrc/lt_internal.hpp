@@ -197,6 +197,7 @@ struct RenderParams {
     const void* nodes;   // NodeD<double>
     const lt_surface_material* mats;
     const lt_point_light* lights;
+    const int16_t* links;   // [8][2][n_nodes] front-to-back threading of the BVH per direction sign pattern (nearest_bvh_ordered)
     int n_tris, n_nodes, n_lights;
     int W, H, S, D;
     double cam[3], f_distance;
@@ -278,10 +279,10 @@ hipError_t launch_log_part2(const LogReduceParams& L, hipStream_t s);
 hipError_t launch_log_reduce(const LogReduceParams& L, hipStream_t s);
 uint32_t log_part_item();   // records per partition work item (the log capacity is a multiple of it)
 
-// use_bvh: 0 brute force, 1 BVH, 2 march grid (G; falls back to the BVH for origins outside the grid)
+// use_bvh: 0 brute force, 1 BVH, 2 / 3 march grid (G; falls back to the BVH for origins outside the grid), 4 BVH front to back (links)
 hipError_t launch_intersect_rays(const void* tris, const void* nodes, int n_tris, int n_nodes,
                                  const double* o, const double* d, const double* tmax, size_t n,
-                                 int use_bvh, const MarchGrid* G, int32_t* prim, double* t, hipStream_t s);
+                                 int use_bvh, const MarchGrid* G, const int16_t* links, int32_t* prim, double* t, hipStream_t s);
 hipError_t launch_triangle_intersect(const double* o, const double* d, const double* tris, size_t n,
                                      double* t, hipStream_t s);
 hipError_t launch_intersect_bounds(const double* o, const double* d, const double* tmax,

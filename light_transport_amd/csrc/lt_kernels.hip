@@ -347,6 +347,44 @@ LT_DEV void nearest_bvh(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes,
     prim = bi; t_out = bi >= 0 ? bt : Mx<R>::inf();
 }
 
+// The same search in FRONT-TO-BACK order -- the reference enters the child on the ray's side of the split plane first
+// (S/bvh_new.py:455-458: `if dir_is_neg[node.axis]` the second child, else the first) so that the nearest hit found early
+// prunes the far boxes -- still without a stack: for each of the 8 sign patterns of a direction the host threads the tree
+// once (lt_api.cpp: bvh_octant_links): first[i] = the child of interior node i the ray meets first, after[i] = where the
+// search continues once the subtree of i is done (its sibling, or its parent's continuation; n_nodes = finished).
+// `links` points at this ray's pattern: first[0 .. n), after[0 .. n).  The result does not depend on the order (nearest
+// hit, ties to the lower primitive index), only the number of boxes and triangles tested does.
+// ANY: stop at the first accepted hit (shadow rays: is anything nearer than tmax?).
+template <typename R, bool ANY = false>
+LT_DEV void nearest_bvh_ordered(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes, const int16_t* links, const R* o,
+                                const R* d, R tmax, int& prim, R& t_out)
+{
+    int bi = -1; R bt = tmax;
+    const R inv_d[3] = {(R)1 / d[0], (R)1 / d[1], (R)1 / d[2]};  // S/bvh_new.py:418
+    const R slack = box_widen<R>();
+    const int16_t* first = links; const int16_t* after = links + n_nodes;
+    int cur = 0;
+    while (cur < n_nodes) {
+        const NodeD<R>* nd = &nodes[cur];
+        const R lo[3] = {nd->lo[0], nd->lo[1], nd->lo[2]};
+        const R hi[3] = {nd->hi[0], nd->hi[1], nd->hi[2]};
+        const int np = nd->n_prims, off = nd->offset;
+        if (box_hit(lo, hi, o, inv_d, bt * slack)) {
+            if (np > 0) {
+                for (int k = 0; k < np; k++) consider(tris, off + k, o, d, bi, bt);
+                if (ANY && bi >= 0) break;
+                cur = after[cur];
+            } else {
+                cur = first[cur];
+            }
+        } else {
+            cur = after[cur];
+        }
+    }
+    prim = bi; t_out = bi >= 0 ? bt : Mx<R>::inf();
+}
+LT_DEV int ray_octant(const double* d) { return (d[0] < 0 ? 1 : 0) | (d[1] < 0 ? 2 : 0) | (d[2] < 0 ? 4 : 0); }
+
 template <typename R>
 LT_DEV void nearest_brute(const TriD<R>* tris, int n_tris, const R* o, const R* d, R tmax,
                           int& prim, R& t_out)
@@ -1237,7 +1275,7 @@ hipError_t launch_walk(const WalkParams& Pin, const Variant& v, const LaunchCfg&
 // ---------------------------------------------------------------------------
 __global__ void k_intersect_rays(const TriD<double>* tris, const NodeD<double>* nodes, int n_tris, int n_nodes,
                                  const double* o, const double* d, const double* tmax, size_t n, int use_bvh,
-                                 const MarchGrid G, int32_t* prim, double* t)
+                                 const MarchGrid G, const int16_t* links, int32_t* prim, double* t)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (use_bvh == 2) {     // the walk's wave-cooperative march (256 threads per workgroup: four waves)
@@ -1254,7 +1292,8 @@ __global__ void k_intersect_rays(const TriD<double>* tris, const NodeD<double>* 
     double oo[3] = {o[3 * i], o[3 * i + 1], o[3 * i + 2]}, dd[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
     double tm = tmax ? tmax[i] : __builtin_huge_val();
     int pi; double tt;
-    if (use_bvh == 3) nearest_march(tris, nodes, n_nodes, G, oo, dd, tm, 0.0, pi, tt);      // the same march, lane by lane
+    if (use_bvh == 4) nearest_bvh_ordered(tris, nodes, n_nodes, links + ray_octant(dd) * 2 * n_nodes, oo, dd, tm, pi, tt);   // front to back (the renderers' order)
+    else if (use_bvh == 3) nearest_march(tris, nodes, n_nodes, G, oo, dd, tm, 0.0, pi, tt);      // the same march, lane by lane
     else if (use_bvh) nearest_bvh(tris, nodes, n_nodes, oo, dd, tm, pi, tt);
     else nearest_brute(tris, n_tris, oo, dd, tm, pi, tt);
     prim[i] = pi; t[i] = tt;
@@ -1554,7 +1593,7 @@ LT_DEV void mark_unused(double* rand_0, size_t base, int from, int D)  // :36-38
 
 // cast_one_shadow_ray (S/light_samples.py:36-61): radiance * brdf * geometry term * area of light sample `choice`
 // as seen from X (offset along n); false when the sample is occluded.
-__device__ __forceinline__ bool shadow_direct(const RenderParams& P, const TriD<double>* tris, const NodeD<double>* nodes,
+__device__ __forceinline__ bool shadow_direct(const RenderParams& P, const TriD<double>* tris, const NodeD<double>* nodes, const int16_t* links,
                                               const double X[3], const double n[3], const lt_surface_material& M,
                                               int choice, double out[3])
 {
@@ -1564,9 +1603,12 @@ __device__ __forceinline__ bool shadow_direct(const RenderParams& P, const TriD<
     double v[3] = {lt.source[0] - so[0], lt.source[1] - so[1], lt.source[2] - so[2]};
     const double mag = ::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
     const double sd[3] = {v[0] / mag, v[1] / mag, v[2] / mag};
+    // (the reference takes the nearest hit of the shadow ray and asks whether it lies at mag - EPSILON or beyond, :49-52: the
+    // sample is hidden exactly when SOME triangle is hit nearer than that, so the search stops at the first one it finds)
     int sp; double st;
-    nearest_bvh(tris, nodes, P.n_nodes, so, sd, inf, sp, st);
-    if (!(st >= mag - eps)) return false;
+    nearest_bvh_ordered<double, true>(tris, nodes, P.n_nodes, links + ray_octant(sd) * 2 * P.n_nodes, so, sd, mag - eps, sp, st);
+    (void)inf;
+    if (sp >= 0) return false;
     const double cos_t = dot3(n, sd);
     const double nsd[3] = {-sd[0], -sd[1], -sd[2]};
     const double cos_p = dot3(lt.normal, nsd);
@@ -1574,6 +1616,27 @@ __device__ __forceinline__ bool shadow_direct(const RenderParams& P, const TriD<
 #pragma unroll
     for (int k = 0; k < 3; k++) out[k] = (lt.radiance[k] * (M.diffuse[k] * inv_pi)) * geom * lt.total_area;
     return true;
+}
+
+// cos x for |x| <= 1 + rounding (the reference takes the cosine of a DOT PRODUCT of unit vectors, quirk B5): Taylor series to
+// x^24 / 24!, truncation < 2e-26 -- OCML's general cos carries a Payne-Hanek reduction for huge arguments and its pow a log / exp pair with
+// double-double arithmetic; inlined into the render kernels they cost ~100 VGPRs for one Schlick term
+__device__ __forceinline__ double cos_unit(double x)
+{
+    const double z = x * x;
+    double p = 1.6117373109360196e-24;                     //  1/24!
+    p = __builtin_fma(p, z, -8.8967913924505741e-22);      // -1/22!
+    p = __builtin_fma(p, z, 4.1103176233121648e-19);       //  1/20!
+    p = __builtin_fma(p, z, -1.5619206968586225e-16);      // -1/18!
+    p = __builtin_fma(p, z, 4.7794773323873853e-14);       //  1/16!
+    p = __builtin_fma(p, z, -1.1470745597729725e-11);      // -1/14!
+    p = __builtin_fma(p, z, 2.0876756987868099e-09);       //  1/12!
+    p = __builtin_fma(p, z, -2.7557319223985891e-07);      // -1/10!
+    p = __builtin_fma(p, z, 2.4801587301587302e-05);       //  1/8!
+    p = __builtin_fma(p, z, -1.3888888888888889e-03);      // -1/6!
+    p = __builtin_fma(p, z, 4.1666666666666664e-02);       //  1/4!
+    p = __builtin_fma(p, z, -0.5);
+    return __builtin_fma(p, z, 1.0);
 }
 
 // mirror (:82-85) and glass (:86-119, kept as written, quirk B5) branches of trace_path: new ray in o, d
@@ -1585,7 +1648,9 @@ __device__ __forceinline__ void specular_bounce(const lt_surface_material& M, co
         const double n1 = inside ? M.ior : 1.0, n2 = inside ? 1.0 : M.ior;
         const double R0 = ((n1 - n2) / (n1 + n2)) * ((n1 - n2) / (n1 + n2));
         const double theta = dot3(d, n);
-        const double refl_prob = R0 + (1 - R0) * ::pow(1 - ::cos(theta), 5.0);
+        // (theta is a dot product of unit vectors; x^5 by three products: within 2 ulp of pow(x, 5.0), the render's pins hold to 1e-9)
+        const double om = 1 - cos_unit(theta), om2 = om * om;
+        const double refl_prob = R0 + (1 - R0) * (om2 * om2 * om);
         double Nr = M.ior;
         if (theta > 0) Nr = 1 / Nr;
         Nr = 1 / Nr;
@@ -1606,70 +1671,113 @@ __device__ __forceinline__ void specular_bounce(const lt_surface_material& M, co
 }
 
 
-__global__ void __launch_bounds__(64) k_render_surface(const RenderParams P)
+// One lane per PATH (pixel, sample), 256 lanes per workgroup: a workgroup owns PPB = max(1, 256 / S) whole pixels, its lanes
+// trace their paths side by side, park the radiance in LDS, and one lane per pixel then adds its samples in ascending order --
+// the reference's own order of summation (:148-164), so the image is what the sample loop of round 1-3's kernel gave, bit for
+// bit.  (That kernel ran one lane per pixel over all its samples: 90 000 lanes for the notebook's 300 x 300 render, a third of
+// the device's lanes for 50 sequential paths each.)  Pixels with more than 256 samples take several rounds.  The scene tables
+// (triangles, BVH nodes, materials: 7 KB for the notebook's scene) are staged in LDS when they fit 48 KiB (LDS_TABLES); the
+// 2000 point lights (160 KB) and the random tables stay in global memory.
+constexpr int kRenderThreads = 256;
+template <bool LDS_TABLES>
+__global__ void __launch_bounds__(kRenderThreads, 2) k_render_surface(const RenderParams P)
 {
-    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= P.W * P.H) return;
-    const int i = pix / P.W, j = pix % P.W;
-    const TriD<double>* tris = reinterpret_cast<const TriD<double>*>(P.tris);
-    const NodeD<double>* nodes = reinterpret_cast<const NodeD<double>*>(P.nodes);
-    const double eps = 1e-6, inv_pi = 0.3183098861837907, inf = __builtin_huge_val();
-    double color[3] = {0, 0, 0};
-    for (int smp = 0; smp < P.S; smp++) {
-        const size_t base = (((size_t)i * P.W + j) * P.S + smp) * (size_t)P.D;
-        // camera ray, :152-160 (anti-alias jitter re-uses the bounce-0 uniform for x and y)
-        double o[3] = {P.cam[0], P.cam[1], P.cam[2]};
-        const double jit = P.rand_0[base];
-        double d[3] = {P.xs[j] + jit / (double)P.W - o[0], P.ys[i] + jit / (double)P.H - o[1], P.f_distance - o[2]};
-        normalize3(d);
-        double thr[3] = {1, 1, 1}, L[3] = {0, 0, 0};
-        for (int bounce = 0;;) {
-            if (bounce >= P.D) break;                                   // :24-26
-            const double r0 = P.rand_0[base + bounce], r1 = P.rand_1[base + bounce];
-            int prim; double t;
-            nearest_bvh(tris, nodes, P.n_nodes, o, d, inf, prim, t);    // hit_object, :32
-            if (prim < 0) { mark_unused(P.rand_0, base, bounce, P.D); break; }
-            const lt_surface_material M = P.mats[prim];
-            double n[3] = {tris[prim].n[0], tris[prim].n[1], tris[prim].n[2]};
-            const double X[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
-            if (M.is_light) { L[0] += M.emission * thr[0]; L[1] += M.emission * thr[1]; L[2] += M.emission * thr[2]; }
-            bool inside = false;
-            if (dot3(n, d) > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; inside = true; }   // :48-51
-            if (M.is_diffuse) {
-                // direct light: cast_one_shadow_ray, S/light_samples.py:36-61
-                double direct[3];
-                if (shadow_direct(P, tris, nodes, X, n, M, P.light_choice[base + bounce], direct)) {
-#pragma unroll
-                    for (int k = 0; k < 3; k++) L[k] += thr[k] * direct[k];
-                }
-                // indirect: cosine lobe, :63-80
-                double o4[4];
-                cosine_hemi(n, d, r0, r1, o4);
-                if (o4[3] == 0) { mark_unused(P.rand_0, base, bounce + 1, P.D); break; }
-                const double cos_theta = o4[0] * n[0] + o4[1] * n[1] + o4[2] * n[2];
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    thr[k] *= (M.diffuse[k] * inv_pi) * cos_theta / o4[3];
-                    o[k] = X[k] + eps * o4[k];
-                    d[k] = o4[k];
-                }
-            } else if (M.is_mirror || M.transmission > 0.0) {           // :82-119
-                specular_bounce(M, X, n, inside, r0, o, d);
-            } else break;                                               // :121-123
-            if (bounce > 5) {                                           // russian roulette, :126-132
-                const double rr = ::fmax(0.05, 1 - thr[1]);
-                if (r0 < rr) { mark_unused(P.rand_0, base, bounce + 1, P.D); break; }
-                thr[0] /= 1 - rr; thr[1] /= 1 - rr; thr[2] /= 1 - rr;
-            }
-            bounce++;
-        }
-        color[0] += L[0]; color[1] += L[1]; color[2] += L[2];
+    extern __shared__ __attribute__((aligned(16))) unsigned char r_lds[];
+    double* s_L = reinterpret_cast<double*>(r_lds);                                       // [256][3] radiance of the lanes' paths
+    const size_t off_t = (size_t)kRenderThreads * 3 * sizeof(double);
+    const size_t off_n = off_t + (size_t)P.n_tris * sizeof(TriD<double>), off_m = off_n + (size_t)P.n_nodes * sizeof(NodeD<double>);
+    const TriD<double>* tris = LDS_TABLES ? reinterpret_cast<const TriD<double>*>(r_lds + off_t) : reinterpret_cast<const TriD<double>*>(P.tris);
+    const NodeD<double>* nodes = LDS_TABLES ? reinterpret_cast<const NodeD<double>*>(r_lds + off_n) : reinterpret_cast<const NodeD<double>*>(P.nodes);
+    const lt_surface_material* mats = LDS_TABLES ? reinterpret_cast<const lt_surface_material*>(r_lds + off_m) : P.mats;
+    const size_t off_k = off_m + (size_t)P.n_tris * sizeof(lt_surface_material);
+    const int16_t* links = LDS_TABLES ? reinterpret_cast<const int16_t*>(r_lds + off_k) : P.links;
+    if constexpr (LDS_TABLES) {
+        lds_copy(r_lds + off_k, P.links, (size_t)((16 * P.n_nodes * 2 + 3) / 4) * 4);
+        lds_copy(r_lds + off_t, P.tris, (size_t)P.n_tris * sizeof(TriD<double>));
+        lds_copy(r_lds + off_n, P.nodes, (size_t)P.n_nodes * sizeof(NodeD<double>));
+        lds_copy(r_lds + off_m, P.mats, (size_t)P.n_tris * sizeof(lt_surface_material));
+        __syncthreads();
     }
+    const double eps = 1e-6, inv_pi = 0.3183098861837907, inf = __builtin_huge_val();
+    const int tid = threadIdx.x;
+    const int chunk = P.S < kRenderThreads ? P.S : kRenderThreads;       // samples of one pixel traced per round
+    const int ppb = kRenderThreads / chunk;                              // whole pixels per workgroup
+    const int pl = tid / chunk, sl = tid % chunk;                        // this lane's pixel (local) and sample slot
+    const int pix = blockIdx.x * ppb + pl;
+    const bool owner = tid < ppb && blockIdx.x * ppb + tid < P.W * P.H;  // lane tid sums local pixel tid
+    double color[3] = {0, 0, 0};
+    for (int s0 = 0; s0 < P.S; s0 += chunk) {
+        const int smp = s0 + sl;
+        double L[3] = {0, 0, 0};
+        if (pl < ppb && pix < P.W * P.H && smp < P.S) {
+            const int i = pix / P.W, j = pix % P.W;
+            const size_t base = (((size_t)i * P.W + j) * P.S + smp) * (size_t)P.D;
+            // camera ray, :152-160 (anti-alias jitter re-uses the bounce-0 uniform for x and y)
+            double o[3] = {P.cam[0], P.cam[1], P.cam[2]};
+            const double jit = P.rand_0[base];
+            double d[3] = {P.xs[j] + jit / (double)P.W - o[0], P.ys[i] + jit / (double)P.H - o[1], P.f_distance - o[2]};
+            normalize3(d);
+            double thr[3] = {1, 1, 1};
+            for (int bounce = 0;;) {
+                if (bounce >= P.D) break;                                   // :24-26
+                const double r0 = P.rand_0[base + bounce], r1 = P.rand_1[base + bounce];
+                int prim; double t;
+                nearest_bvh_ordered(tris, nodes, P.n_nodes, links + ray_octant(d) * 2 * P.n_nodes, o, d, inf, prim, t);    // hit_object, :32
+                if (prim < 0) { mark_unused(P.rand_0, base, bounce, P.D); break; }
+                const lt_surface_material M = mats[prim];
+                double n[3] = {tris[prim].n[0], tris[prim].n[1], tris[prim].n[2]};
+                const double X[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+                if (M.is_light) { L[0] += M.emission * thr[0]; L[1] += M.emission * thr[1]; L[2] += M.emission * thr[2]; }
+                bool inside = false;
+                if (dot3(n, d) > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; inside = true; }   // :48-51
+                if (M.is_diffuse) {
+                    // direct light: cast_one_shadow_ray, S/light_samples.py:36-61
+                    double direct[3];
+                    if (shadow_direct(P, tris, nodes, links, X, n, M, P.light_choice[base + bounce], direct)) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {                                       // :164-166
-        double c = color[k] / (double)P.S;
-        c = c < 0 ? 0.0 : (c > 1 ? 1.0 : c);
-        P.image[(size_t)pix * 3 + k] += 0.25 * c;
+                        for (int k = 0; k < 3; k++) L[k] += thr[k] * direct[k];
+                    }
+                    // indirect: cosine lobe, :63-80
+                    double o4[4];
+                    cosine_hemi(n, d, r0, r1, o4);
+                    if (o4[3] == 0) { mark_unused(P.rand_0, base, bounce + 1, P.D); break; }
+                    const double cos_theta = o4[0] * n[0] + o4[1] * n[1] + o4[2] * n[2];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        thr[k] *= (M.diffuse[k] * inv_pi) * cos_theta / o4[3];
+                        o[k] = X[k] + eps * o4[k];
+                        d[k] = o4[k];
+                    }
+                } else if (M.is_mirror || M.transmission > 0.0) {           // :82-119
+                    specular_bounce(M, X, n, inside, r0, o, d);
+                } else break;                                               // :121-123
+                if (bounce > 5) {                                           // russian roulette, :126-132
+                    const double rr = ::fmax(0.05, 1 - thr[1]);
+                    if (r0 < rr) { mark_unused(P.rand_0, base, bounce + 1, P.D); break; }
+                    thr[0] /= 1 - rr; thr[1] /= 1 - rr; thr[2] /= 1 - rr;
+                }
+                bounce++;
+            }
+        }
+        s_L[tid * 3] = L[0]; s_L[tid * 3 + 1] = L[1]; s_L[tid * 3 + 2] = L[2];
+        __syncthreads();
+        if (owner) {        // color += light, sample by sample (:162)
+            const int ns = P.S - s0 < chunk ? P.S - s0 : chunk;
+            for (int q = 0; q < ns; q++) {
+                const double* l = s_L + (size_t)(tid * chunk + q) * 3;
+                color[0] += l[0]; color[1] += l[1]; color[2] += l[2];
+            }
+        }
+        __syncthreads();
+    }
+    if (owner) {
+        const size_t px = (size_t)blockIdx.x * ppb + tid;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {                                       // :164-166
+            double c = color[k] / (double)P.S;
+            c = c < 0 ? 0.0 : (c > 1 ? 1.0 : c);
+            P.image[px * 3 + k] += 0.25 * c;
+        }
     }
 }
 
@@ -1717,7 +1825,7 @@ __global__ void __launch_bounds__(64) k_render_surface_old(const RenderParams P)
                 const double r0 = P.rand_0[base + F.bounce], r1 = P.rand_1[base + F.bounce];
                 F.r0 = r0;
                 int prim; double t;
-                nearest_bvh(tris, nodes, P.n_nodes, o, d, inf, prim, t);
+                nearest_bvh_ordered(tris, nodes, P.n_nodes, P.links + ray_octant(d) * 2 * P.n_nodes, o, d, inf, prim, t);
                 if (prim < 0) { mark_unused(P.rand_0, base, F.bounce, P.D); done = true; }
                 else {
                     const lt_surface_material M = P.mats[prim];
@@ -1730,7 +1838,7 @@ __global__ void __launch_bounds__(64) k_render_surface_old(const RenderParams P)
                     bool inside = false;
                     if (dot3(n, d) > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; inside = true; }
                     if (M.is_diffuse) {
-                        if (!shadow_direct(P, tris, nodes, X, n, M, choice[n_shadow % (unsigned)P.choices], F.direct))
+                        if (!shadow_direct(P, tris, nodes, P.links, X, n, M, choice[n_shadow % (unsigned)P.choices], F.direct))
                             F.direct[0] = F.direct[1] = F.direct[2] = 0;
                         n_shadow++;
                         double o4[4];
@@ -1779,23 +1887,31 @@ hipError_t launch_render_surface(const RenderParams& P, hipStream_t s)
 {
     const int n = P.W * P.H;
     if (n <= 0) return hipSuccess;
-    if (P.variant == 1) hipLaunchKernelGGL(k_render_surface_old, dim3((n + 63) / 64), dim3(64), 0, s, P);
-    else hipLaunchKernelGGL(k_render_surface, dim3((n + 63) / 64), dim3(64), 0, s, P);
+    if (P.variant == 1) { hipLaunchKernelGGL(k_render_surface_old, dim3((n + 63) / 64), dim3(64), 0, s, P); return hipGetLastError(); }
+    const int chunk = P.S < kRenderThreads ? P.S : kRenderThreads, ppb = kRenderThreads / chunk;
+    const size_t tables = (size_t)P.n_tris * (sizeof(TriD<double>) + sizeof(lt_surface_material)) + (size_t)P.n_nodes * sizeof(NodeD<double>) +
+                          (size_t)((16 * P.n_nodes * 2 + 3) / 4) * 4;
+    const size_t lds_l = (size_t)kRenderThreads * 3 * sizeof(double);
+    if (tables <= 48 * 1024)
+        hipLaunchKernelGGL(k_render_surface<true>, dim3((n + ppb - 1) / ppb), dim3(kRenderThreads), lds_l + tables, s, P);
+    else
+        hipLaunchKernelGGL(k_render_surface<false>, dim3((n + ppb - 1) / ppb), dim3(kRenderThreads), lds_l, s, P);
     return hipGetLastError();
 }
 
 static inline unsigned nblk(size_t n, unsigned t) { return (unsigned)((n + t - 1) / t); }
 
 hipError_t launch_intersect_rays(const void* tris, const void* nodes, int n_tris, int n_nodes, const double* o,
-                                 const double* d, const double* tmax, size_t n, int use_bvh, const MarchGrid* G, int32_t* prim,
-                                 double* t, hipStream_t s)
+                                 const double* d, const double* tmax, size_t n, int use_bvh, const MarchGrid* G, const int16_t* links,
+                                 int32_t* prim, double* t, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
     MarchGrid g;
-    if (G) g = *G; else { memset(&g, 0, sizeof g); if (use_bvh >= 2) use_bvh = 1; }
+    if (use_bvh == 4 && !links) use_bvh = 1;
+    if (G) g = *G; else { memset(&g, 0, sizeof g); if (use_bvh == 2 || use_bvh == 3) use_bvh = 1; }
     hipLaunchKernelGGL(k_intersect_rays, dim3(nblk(n, 256)), dim3(256), 0, s,
                        reinterpret_cast<const TriD<double>*>(tris), reinterpret_cast<const NodeD<double>*>(nodes),
-                       n_tris, n_nodes, o, d, tmax, n, use_bvh, g, prim, t);
+                       n_tris, n_nodes, o, d, tmax, n, use_bvh, g, links, prim, t);
     return hipGetLastError();
 }
 hipError_t launch_triangle_intersect(const double* o, const double* d, const double* tris, size_t n, double* t,

@@ -74,7 +74,7 @@ def test_g4_nearest_hit(ctx, golden_dir):
     verts = B.triangles_array(ordered)
     key = {tuple(np.round(v.ravel(), 9)): i for i, v in enumerate(g4["verts"])}
     back = np.array([key[tuple(np.round(v.ravel(), 9))] for v in verts])
-    for use_bvh in (True, False):
+    for use_bvh in (True, False, 4):        # 4: the BVH front to back (near child first, bvh_new.py:455-458), the renderers' order
         prim, t = B.intersect_bvh_batch(g4["origins"], g4["dirs"], ordered, linear, g4["tmax"], use_bvh, ctx)
         got = np.where(prim >= 0, back[np.maximum(prim, 0)], -1)
         np.testing.assert_array_equal(got, g4["prim"])
@@ -557,7 +557,7 @@ def test_large_mesh_in_global_memory(ctx):
     p0, t0 = B.intersect_bvh_batch(o, d, ordered, linear, tmax, False, ctx)
     np.testing.assert_array_equal(p1, p0); np.testing.assert_array_equal(t1, t0)
     # the grid march (what the walk uses for this mesh) answers every ray exactly as the brute-force scan does
-    for form in (2, 3):          # 2: the walk's wave-cooperative service, 3: the same march lane by lane
+    for form in (2, 3, 4):       # 2: the walk's wave-cooperative service, 3: the same march lane by lane; 4: the BVH front to back
         p2, t2 = B.intersect_bvh_batch(o, d, ordered, linear, tmax, form, ctx)
         np.testing.assert_array_equal(p2, p0); np.testing.assert_array_equal(t2, t0)
     po, to = prob.oracle().intersect_rays(o, d, tmax, use_bvh=True)
@@ -666,6 +666,11 @@ def test_deep_bvh_is_accepted(ctx):
     p1, t1 = ctx.intersect_rays(o, d, None, 1)
     p0, t0 = ctx.intersect_rays(o, d, None, 0)
     np.testing.assert_array_equal(p1, p0); np.testing.assert_array_equal(t1, t0)
+    p4, t4 = ctx.intersect_rays(o, d, None, 4)          # front to back, threaded per direction sign pattern: no stack either
+    np.testing.assert_array_equal(p4, p0); np.testing.assert_array_equal(t4, t0)
+    tm = np.random.RandomState(8).uniform(0.2, 6.0, n)  # ... and with a finite reach (shadow rays, hops)
+    p4, t4 = ctx.intersect_rays(o, d, tm, 4); p0b, t0b = ctx.intersect_rays(o, d, tm, 0)
+    np.testing.assert_array_equal(p4, p0b); np.testing.assert_array_equal(t4, t0b)
     assert (p0 >= 0).mean() > 0.4 and len(np.unique(p0[p0 >= 0])) == T          # every link of the chain is somebody's nearest hit
     assert (p0[p0 >= 0] != k[p0 >= 0]).mean() > 0.3                             # ... and not always the one aimed at: an earlier link was in the way
     nodes["offset"][0] = 1                          # ... while a malformed tree is still refused
