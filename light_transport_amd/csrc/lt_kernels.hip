@@ -1787,99 +1787,137 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_surface(const Rend
 // starts after bounce 3 (:127) and the pixel is overwritten with clip(mean) (:167).  The recursion is unrolled into an
 // explicit per-lane stack of (throughput, light, direct, r0, bounce) frames, visited in the reference's depth-first
 // order so that the +inf markers written into rand_0 are read back exactly where the reference reads them.
-struct OldFrame { double thr[3], L[3], direct[3], r0; int bounce; };
-
-__global__ void __launch_bounds__(64) k_render_surface_old(const RenderParams P)
+// One lane per PATH (pixel, sample) as in k_render_surface, one wave per workgroup; the frame being executed lives in
+// registers, the frames of its callers in LDS ([depth][field][lane]: at most D of them, 45 KiB for the notebook's depth 8) --
+// rounds 1-3 kept the whole stack of 25 frames in scratch memory (2288 B per lane) and looped over a pixel's samples in one lane.
+constexpr int kOldThreads = 64, kOldFields = 11;      // thr[3], L[3], direct[3], r0, bounce
+__global__ void __launch_bounds__(kOldThreads) k_render_surface_old(const RenderParams P)
 {
-    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= P.W * P.H) return;
-    const int i = pix / P.W, j = pix % P.W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char r_lds[];
+    double* s_L = reinterpret_cast<double*>(r_lds);                       // [64][3]
+    double* s_st = s_L + kOldThreads * 3;                                 // [D][kOldFields][64]
     const TriD<double>* tris = reinterpret_cast<const TriD<double>*>(P.tris);
     const NodeD<double>* nodes = reinterpret_cast<const NodeD<double>*>(P.nodes);
     const double eps = 1e-6, inv_pi = 0.3183098861837907, inf = __builtin_huge_val();
-    OldFrame st[kRenderOldMaxDepth + 1];
+    const int tid = threadIdx.x;
+    const int chunk = P.S < kOldThreads ? P.S : kOldThreads, ppb = kOldThreads / chunk;
+    const int pl = tid / chunk, sl = tid % chunk;
+    const int pix = blockIdx.x * ppb + pl;
+    const bool owner = tid < ppb && blockIdx.x * ppb + tid < P.W * P.H;
     double color[3] = {0, 0, 0};
-    for (int smp = 0; smp < P.S; smp++) {
-        const size_t sample = ((size_t)i * P.W + j) * P.S + smp;
-        const size_t base = sample * (size_t)P.D;
-        const int32_t* choice = P.light_choice + sample * (size_t)P.choices;
-        unsigned n_shadow = 0;
-        double o[3] = {P.cam[0], P.cam[1], P.cam[2]};
-        const double jit = P.rand_0[base];                               // :158-159
-        double d[3] = {P.xs[j] + jit / (double)P.W - o[0], P.ys[i] + jit / (double)P.H - o[1], P.f_distance - o[2]};
-        normalize3(d);
-        int depth = 0;
-        bool resume = false;
+    for (int s0 = 0; s0 < P.S; s0 += chunk) {
+        const int smp = s0 + sl;
         double ret[3] = {0, 0, 0};
-        st[0] = OldFrame{{1, 1, 1}, {0, 0, 0}, {0, 0, 0}, 0.0, 0};
-        for (;;) {
-            OldFrame& F = st[depth];
-            bool done = false;
-            if (resume) {                                                // back from trace_path(bounce + 1), :78-80
-                resume = false;
+        if (pl < ppb && pix < P.W * P.H && smp < P.S) {
+            const int i = pix / P.W, j = pix % P.W;
+            const size_t sample = ((size_t)i * P.W + j) * P.S + smp;
+            const size_t base = sample * (size_t)P.D;
+            const int32_t* choice = P.light_choice + sample * (size_t)P.choices;
+            unsigned n_shadow = 0;
+            double o[3] = {P.cam[0], P.cam[1], P.cam[2]};
+            const double jit = P.rand_0[base];                               // :158-159
+            double d[3] = {P.xs[j] + jit / (double)P.W - o[0], P.ys[i] + jit / (double)P.H - o[1], P.f_distance - o[2]};
+            normalize3(d);
+            int depth = 0;
+            bool resume = false;
+            // the frame in execution
+            double f_thr[3] = {1, 1, 1}, f_L[3] = {0, 0, 0}, f_direct[3] = {0, 0, 0}, f_r0 = 0.0;
+            int f_bounce = 0;
+            for (;;) {
+                bool done = false;
+                if (resume) {                                                // back from trace_path(bounce + 1), :78-80
+                    resume = false;
 #pragma unroll
-                for (int k = 0; k < 3; k++) F.L[k] += (F.direct[k] + F.thr[k] * ret[k]);
-            } else if (F.bounce >= P.D) {                                // :24-25
-                done = true;
-            } else {
-                const double r0 = P.rand_0[base + F.bounce], r1 = P.rand_1[base + F.bounce];
-                F.r0 = r0;
-                int prim; double t;
-                nearest_bvh_ordered(tris, nodes, P.n_nodes, P.links + ray_octant(d) * 2 * P.n_nodes, o, d, inf, prim, t);
-                if (prim < 0) { mark_unused(P.rand_0, base, F.bounce, P.D); done = true; }
-                else {
-                    const lt_surface_material M = P.mats[prim];
-                    double n[3] = {tris[prim].n[0], tris[prim].n[1], tris[prim].n[2]};
-                    const double X[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
-                    if (M.is_light && F.bounce == 0) {                   // :45-46
+                    for (int k = 0; k < 3; k++) f_L[k] += (f_direct[k] + f_thr[k] * ret[k]);
+                } else if (f_bounce >= P.D) {                                // :24-25
+                    done = true;
+                } else {
+                    const double r0 = P.rand_0[base + f_bounce], r1 = P.rand_1[base + f_bounce];
+                    f_r0 = r0;
+                    int prim; double t;
+                    nearest_bvh_ordered(tris, nodes, P.n_nodes, P.links + ray_octant(d) * 2 * P.n_nodes, o, d, inf, prim, t);
+                    if (prim < 0) { mark_unused(P.rand_0, base, f_bounce, P.D); done = true; }
+                    else {
+                        const lt_surface_material M = P.mats[prim];
+                        double n[3] = {tris[prim].n[0], tris[prim].n[1], tris[prim].n[2]};
+                        const double X[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+                        if (M.is_light && f_bounce == 0) {                   // :45-46
 #pragma unroll
-                        for (int k = 0; k < 3; k++) F.L[k] += M.emission * F.thr[k];
-                    }
-                    bool inside = false;
-                    if (dot3(n, d) > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; inside = true; }
-                    if (M.is_diffuse) {
-                        if (!shadow_direct(P, tris, nodes, P.links, X, n, M, choice[n_shadow % (unsigned)P.choices], F.direct))
-                            F.direct[0] = F.direct[1] = F.direct[2] = 0;
-                        n_shadow++;
-                        double o4[4];
-                        cosine_hemi(n, d, r0, r1, o4);
-                        if (o4[3] == 0) { mark_unused(P.rand_0, base, F.bounce + 1, P.D); done = true; }
-                        else {
-                            const double cos_theta = o4[0] * n[0] + o4[1] * n[1] + o4[2] * n[2];
-#pragma unroll
-                            for (int k = 0; k < 3; k++) {
-                                F.thr[k] *= (M.diffuse[k] * inv_pi) * cos_theta / o4[3];
-                                o[k] = X[k] + eps * o4[k];
-                                d[k] = o4[k];
-                            }
-                            const int child = F.bounce + 1;
-                            depth++;                                     // trace_path(scene, ..., ray, bounce + 1, ...), :78
-                            st[depth] = OldFrame{{1, 1, 1}, {0, 0, 0}, {0, 0, 0}, 0.0, child};
-                            continue;
+                            for (int k = 0; k < 3; k++) f_L[k] += M.emission * f_thr[k];
                         }
-                    } else if (M.is_mirror || M.transmission > 0.0) {
-                        specular_bounce(M, X, n, inside, r0, o, d);
-                    } else done = true;                                  // :122-124
-                }
-            }
-            if (!done && F.bounce > 3) {                                 // :127-133
-                const double rr = ::fmax(0.05, 1 - F.thr[1]);
-                if (F.r0 < rr) { mark_unused(P.rand_0, base, F.bounce + 1, P.D); done = true; }
-                else { F.thr[0] /= 1 - rr; F.thr[1] /= 1 - rr; F.thr[2] /= 1 - rr; }
-            }
-            if (!done) { F.bounce++; continue; }
-            ret[0] = F.L[0]; ret[1] = F.L[1]; ret[2] = F.L[2];          // return light, :137
-            if (depth == 0) break;
-            depth--;
-            resume = true;
-        }
-        color[0] += ret[0]; color[1] += ret[1]; color[2] += ret[2];
-    }
+                        bool inside = false;
+                        if (dot3(n, d) > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; inside = true; }
+                        if (M.is_diffuse) {
+                            if (!shadow_direct(P, tris, nodes, P.links, X, n, M, choice[n_shadow % (unsigned)P.choices], f_direct))
+                                f_direct[0] = f_direct[1] = f_direct[2] = 0;
+                            n_shadow++;
+                            double o4[4];
+                            cosine_hemi(n, d, r0, r1, o4);
+                            if (o4[3] == 0) { mark_unused(P.rand_0, base, f_bounce + 1, P.D); done = true; }
+                            else {
+                                const double cos_theta = o4[0] * n[0] + o4[1] * n[1] + o4[2] * n[2];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {                                       // :166-167
-        double c = color[k] / (double)P.S;
-        c = c < 0 ? 0.0 : (c > 1 ? 1.0 : c);
-        P.image[(size_t)pix * 3 + k] = c;
+                                for (int k = 0; k < 3; k++) {
+                                    f_thr[k] *= (M.diffuse[k] * inv_pi) * cos_theta / o4[3];
+                                    o[k] = X[k] + eps * o4[k];
+                                    d[k] = o4[k];
+                                }
+                                // trace_path(scene, ..., ray, bounce + 1, ...), :78 -- the caller's frame goes to LDS
+                                double* fr = s_st + ((size_t)depth * kOldFields) * kOldThreads + tid;
+#pragma unroll
+                                for (int k = 0; k < 3; k++) {
+                                    fr[(size_t)k * kOldThreads] = f_thr[k]; fr[(size_t)(3 + k) * kOldThreads] = f_L[k];
+                                    fr[(size_t)(6 + k) * kOldThreads] = f_direct[k];
+                                    f_thr[k] = 1; f_L[k] = 0; f_direct[k] = 0;
+                                }
+                                fr[(size_t)9 * kOldThreads] = f_r0; fr[(size_t)10 * kOldThreads] = (double)f_bounce;
+                                f_r0 = 0.0; f_bounce = f_bounce + 1;
+                                depth++;
+                                continue;
+                            }
+                        } else if (M.is_mirror || M.transmission > 0.0) {
+                            specular_bounce(M, X, n, inside, r0, o, d);
+                        } else done = true;                                  // :122-124
+                    }
+                }
+                if (!done && f_bounce > 3) {                                 // :127-133
+                    const double rr = ::fmax(0.05, 1 - f_thr[1]);
+                    if (f_r0 < rr) { mark_unused(P.rand_0, base, f_bounce + 1, P.D); done = true; }
+                    else { f_thr[0] /= 1 - rr; f_thr[1] /= 1 - rr; f_thr[2] /= 1 - rr; }
+                }
+                if (!done) { f_bounce++; continue; }
+                ret[0] = f_L[0]; ret[1] = f_L[1]; ret[2] = f_L[2];          // return light, :137
+                if (depth == 0) break;
+                depth--;                                                     // the caller's frame comes back
+                const double* fr = s_st + ((size_t)depth * kOldFields) * kOldThreads + tid;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    f_thr[k] = fr[(size_t)k * kOldThreads]; f_L[k] = fr[(size_t)(3 + k) * kOldThreads];
+                    f_direct[k] = fr[(size_t)(6 + k) * kOldThreads];
+                }
+                f_r0 = fr[(size_t)9 * kOldThreads]; f_bounce = (int)fr[(size_t)10 * kOldThreads];
+                resume = true;
+            }
+        }
+        s_L[tid * 3] = ret[0]; s_L[tid * 3 + 1] = ret[1]; s_L[tid * 3 + 2] = ret[2];
+        __syncthreads();
+        if (owner) {        // color += light, sample by sample (:163)
+            const int ns = P.S - s0 < chunk ? P.S - s0 : chunk;
+            for (int q = 0; q < ns; q++) {
+                const double* l = s_L + (size_t)(tid * chunk + q) * 3;
+                color[0] += l[0]; color[1] += l[1]; color[2] += l[2];
+            }
+        }
+        __syncthreads();
+    }
+    if (owner) {
+        const size_t px = (size_t)blockIdx.x * ppb + tid;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {                                       // :166-167
+            double c = color[k] / (double)P.S;
+            c = c < 0 ? 0.0 : (c > 1 ? 1.0 : c);
+            P.image[px * 3 + k] = c;
+        }
     }
 }
 
@@ -1887,7 +1925,16 @@ hipError_t launch_render_surface(const RenderParams& P, hipStream_t s)
 {
     const int n = P.W * P.H;
     if (n <= 0) return hipSuccess;
-    if (P.variant == 1) { hipLaunchKernelGGL(k_render_surface_old, dim3((n + 63) / 64), dim3(64), 0, s, P); return hipGetLastError(); }
+    if (P.variant == 1) {
+        const int chunk_o = P.S < kOldThreads ? P.S : kOldThreads, ppb_o = kOldThreads / chunk_o;
+        const size_t lds_o = ((size_t)kOldThreads * 3 + (size_t)P.D * kOldFields * kOldThreads) * sizeof(double);      // D <= kRenderOldMaxDepth: <= 137 KiB
+        if (lds_o > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_surface_old), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_o);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k_render_surface_old, dim3((n + ppb_o - 1) / ppb_o), dim3(kOldThreads), lds_o, s, P);
+        return hipGetLastError();
+    }
     const int chunk = P.S < kRenderThreads ? P.S : kRenderThreads, ppb = kRenderThreads / chunk;
     const size_t tables = (size_t)P.n_tris * (sizeof(TriD<double>) + sizeof(lt_surface_material)) + (size_t)P.n_nodes * sizeof(NodeD<double>) +
                           (size_t)((16 * P.n_nodes * 2 + 3) / 4) * 4;
