@@ -192,6 +192,38 @@ LT_DEV void sincos_turn_f64(double xi, double* sn, double* cs)  // sin, cos of 2
     *cs = ((q + 1) & 2) ? -c1 : c1;
 }
 
+// sin, cos of x for |x| <= pi (the renderers' concentric disk map: theta in [-pi/4, 3 pi/4]): reduction by multiples of pi/2
+// (Cody-Waite, two terms: exact for |k| <= 2) and the polynomials above.  OCML's general routines carry a Payne-Hanek
+// reduction for huge arguments and cost the render kernels tens of VGPRs; within 1 ulp of them here.
+LT_DEV void sincos_small_f64(double x, double* sn, double* cs)
+{
+    const double kf = __builtin_rint(x * 0.63661977236758134308);          // x * 2 / pi
+    double a = __builtin_fma(-kf, 1.57079632679489655800e+00, x);           // pi/2, high part
+    a = __builtin_fma(-kf, 6.12323399573676603587e-17, a);                  //       low part
+    const double z = a * a;
+    double ps = -7.6471637318198164759e-13;
+    ps = fma_k(ps, z, 1.6059043836821614599e-10);
+    ps = fma_k(ps, z, -2.5052108385441718775e-08);
+    ps = fma_k(ps, z, 2.7557319223985890653e-06);
+    ps = fma_k(ps, z, -1.9841269841269841270e-04);
+    ps = fma_k(ps, z, 8.3333333333333333333e-03);
+    ps = fma_k(ps, z, -1.6666666666666666667e-01);
+    const double s = __builtin_fma(a * z, ps, a);
+    double pc = 4.7794773323873852974e-14;
+    pc = fma_k(pc, z, -1.1470745597729724714e-11);
+    pc = fma_k(pc, z, 2.0876756987868098979e-09);
+    pc = fma_k(pc, z, -2.7557319223985890653e-07);
+    pc = fma_k(pc, z, 2.4801587301587301587e-05);
+    pc = fma_k(pc, z, -1.3888888888888888889e-03);
+    pc = fma_k(pc, z, 4.1666666666666666667e-02);
+    pc = __builtin_fma(pc, z, -0.5);
+    const double c = __builtin_fma(pc, z, 1.0);
+    const int q = (int)kf & 3;
+    const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
 template <typename R> struct Mx;
 template <> struct Mx<double> {
     static LT_DEV double log(double x) { return ::log(x); }
@@ -355,9 +387,9 @@ LT_DEV void nearest_bvh(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes,
 // `links` points at this ray's pattern: first[0 .. n), after[0 .. n).  The result does not depend on the order (nearest
 // hit, ties to the lower primitive index), only the number of boxes and triangles tested does.
 // ANY: stop at the first accepted hit (shadow rays: is anything nearer than tmax?).
-template <typename R, bool ANY = false>
+template <typename R>
 LT_DEV void nearest_bvh_ordered(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes, const int16_t* links, const R* o,
-                                const R* d, R tmax, int& prim, R& t_out)
+                                const R* d, R tmax, int& prim, R& t_out, bool ANY = false)
 {
     int bi = -1; R bt = tmax;
     const R inv_d[3] = {(R)1 / d[0], (R)1 / d[1], (R)1 / d[2]};  // S/bvh_new.py:418
@@ -763,14 +795,21 @@ template <typename R> LT_DEV void onb(const R* n, R* v2, R* v3)
 }
 
 // concentric_sample_disk, S/utils.py:115-128
-template <typename R> LT_DEV void disk(R u0, R u1, R* d)
+// (LEAN: the surface renderers' build -- sin / cos by sincos_small_f64 instead of the general library routines)
+template <typename R, bool LEAN = false> LT_DEV void disk(R u0, R u1, R* d)
 {
     R ox = (R)2 * u0 - (R)1, oy = (R)2 * u1 - (R)1;
     if (ox == 0 && oy == 0) { d[0] = 0; d[1] = 0; return; }
     R r, theta;
     if (Mx<R>::abs(ox) > Mx<R>::abs(oy)) { r = ox; theta = (R)0.7853981633974483 * (oy / ox); }
     else { r = oy; theta = (R)1.5707963267948966 - (R)0.7853981633974483 * (ox / oy); }
-    d[0] = r * Mx<R>::cos(theta); d[1] = r * Mx<R>::sin(theta);
+    if constexpr (LEAN && sizeof(R) == 8) {
+        double sn, cs;
+        sincos_small_f64(theta, &sn, &cs);
+        d[0] = r * cs; d[1] = r * sn;
+    } else {
+        d[0] = r * Mx<R>::cos(theta); d[1] = r * Mx<R>::sin(theta);
+    }
 }
 
 // cosine_weighted_hemisphere_sampling, S/utils.py:132-161
@@ -789,10 +828,10 @@ template <typename R> LT_DEV void cosine_hemi_frame(const R* n, const R* v2, con
     for (int k = 0; k < 3; k++) out[k] = d[0] * v2[k] + d[1] * v3[k] + oz * n[k];  // :154-157
     out[3] = pdf;
 }
-template <typename R> LT_DEV void cosine_hemi(const R* n, const R* wi_in, R u0, R u1, R* out)
+template <typename R, bool LEAN = false> LT_DEV void cosine_hemi(const R* n, const R* wi_in, R u0, R u1, R* out)
 {
     R wiz = -wi_in[2];  // :133
-    R d[2]; disk(u0, u1, d);
+    R d[2]; disk<R, LEAN>(u0, u1, d);
     R zz = (R)1 - d[0] * d[0] - d[1] * d[1];
     R z = Mx<R>::sqrt(zz > 0 ? zz : (R)0);  // :138
     R oz = z;
@@ -1606,7 +1645,7 @@ __device__ __forceinline__ bool shadow_direct(const RenderParams& P, const TriD<
     // (the reference takes the nearest hit of the shadow ray and asks whether it lies at mag - EPSILON or beyond, :49-52: the
     // sample is hidden exactly when SOME triangle is hit nearer than that, so the search stops at the first one it finds)
     int sp; double st;
-    nearest_bvh_ordered<double, true>(tris, nodes, P.n_nodes, links + ray_octant(sd) * 2 * P.n_nodes, so, sd, mag - eps, sp, st);
+    nearest_bvh_ordered(tris, nodes, P.n_nodes, links + ray_octant(sd) * 2 * P.n_nodes, so, sd, mag - eps, sp, st, true);
     (void)inf;
     if (sp >= 0) return false;
     const double cos_t = dot3(n, sd);
@@ -1679,8 +1718,12 @@ __device__ __forceinline__ void specular_bounce(const lt_surface_material& M, co
 // (triangles, BVH nodes, materials: 7 KB for the notebook's scene) are staged in LDS when they fit 48 KiB (LDS_TABLES); the
 // 2000 point lights (160 KB) and the random tables stay in global memory.
 constexpr int kRenderThreads = 256;
+#ifndef LT_RENDER_WAVES
+#define LT_RENDER_WAVES 4      // waves per SIMD the register allocator leaves room for: 2 (172 VGPRs, no scratch) 7.1 ms, 3 (168 + 12 B)
+                               // 5.2 ms, 4 (128 + 188 B of scratch) 4.6 ms for the 300 x 300 x 50 spp render (profiles/r04e_render_time.log)
+#endif
 template <bool LDS_TABLES>
-__global__ void __launch_bounds__(kRenderThreads, 2) k_render_surface(const RenderParams P)
+__global__ void __launch_bounds__(kRenderThreads, LT_RENDER_WAVES) k_render_surface(const RenderParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char r_lds[];
     double* s_L = reinterpret_cast<double*>(r_lds);                                       // [256][3] radiance of the lanes' paths
@@ -1718,28 +1761,58 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_surface(const Rend
             double d[3] = {P.xs[j] + jit / (double)P.W - o[0], P.ys[i] + jit / (double)P.H - o[1], P.f_distance - o[2]};
             normalize3(d);
             double thr[3] = {1, 1, 1};
+            // ONE traversal site serves both kinds of ray: (o, d) is the ray the next search follows -- the path's own ray, or,
+            // while `shadow`, the shadow ray of the diffuse hit (`hit`, `thit` on the stashed path ray po, pd) whose shading
+            // is completed when the search returns.  Two inlined copies of the traversal cost the kernel 221 VGPRs; the
+            // expressions evaluated are those of trace_path / cast_one_shadow_ray, in the same order.
+            bool shadow = false;
+            int hit = -1; double thit = 0, smag = 0;
+            double po[3] = {0, 0, 0}, pd[3] = {0, 0, 1};
             for (int bounce = 0;;) {
-                if (bounce >= P.D) break;                                   // :24-26
-                const double r0 = P.rand_0[base + bounce], r1 = P.rand_1[base + bounce];
+                if (!shadow && bounce >= P.D) break;                        // :24-26
                 int prim; double t;
-                nearest_bvh_ordered(tris, nodes, P.n_nodes, links + ray_octant(d) * 2 * P.n_nodes, o, d, inf, prim, t);    // hit_object, :32
-                if (prim < 0) { mark_unused(P.rand_0, base, bounce, P.D); break; }
-                const lt_surface_material M = mats[prim];
-                double n[3] = {tris[prim].n[0], tris[prim].n[1], tris[prim].n[2]};
-                const double X[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
-                if (M.is_light) { L[0] += M.emission * thr[0]; L[1] += M.emission * thr[1]; L[2] += M.emission * thr[2]; }
-                bool inside = false;
-                if (dot3(n, d) > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; inside = true; }   // :48-51
-                if (M.is_diffuse) {
-                    // direct light: cast_one_shadow_ray, S/light_samples.py:36-61
-                    double direct[3];
-                    if (shadow_direct(P, tris, nodes, links, X, n, M, P.light_choice[base + bounce], direct)) {
+                nearest_bvh_ordered(tris, nodes, P.n_nodes, links + ray_octant(d) * 2 * P.n_nodes, o, d, shadow ? smag - eps : inf, prim, t, shadow);    // hit_object, :32 / cast_one_shadow_ray
+                const double r0 = P.rand_0[base + bounce], r1 = P.rand_1[base + bounce];
+                if (!shadow) {
+                    if (prim < 0) { mark_unused(P.rand_0, base, bounce, P.D); break; }
+                    const lt_surface_material M = mats[prim];
+                    double n[3] = {tris[prim].n[0], tris[prim].n[1], tris[prim].n[2]};
+                    const double X[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+                    if (M.is_light) { L[0] += M.emission * thr[0]; L[1] += M.emission * thr[1]; L[2] += M.emission * thr[2]; }
+                    bool inside = false;
+                    if (dot3(n, d) > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; inside = true; }   // :48-51
+                    if (M.is_diffuse) {
+                        // direct light: cast_one_shadow_ray, S/light_samples.py:36-61 -- the shadow ray becomes the ray to follow
+                        const lt_point_light lt = P.lights[P.light_choice[base + bounce]];
 #pragma unroll
-                        for (int k = 0; k < 3; k++) L[k] += thr[k] * direct[k];
+                        for (int k = 0; k < 3; k++) { po[k] = o[k]; pd[k] = d[k]; o[k] = X[k] + eps * n[k]; }
+                        double v[3] = {lt.source[0] - o[0], lt.source[1] - o[1], lt.source[2] - o[2]};
+                        smag = ::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                        d[0] = v[0] / smag; d[1] = v[1] / smag; d[2] = v[2] / smag;
+                        hit = prim; thit = t; shadow = true;
+                        continue;
+                    } else if (M.is_mirror || M.transmission > 0.0) {           // :82-119
+                        specular_bounce(M, X, n, inside, r0, o, d);
+                    } else break;                                               // :121-123
+                } else {
+                    // the shadow ray is back: finish the diffuse hit it belongs to
+                    shadow = false;
+                    const lt_surface_material M = mats[hit];
+                    double n[3] = {tris[hit].n[0], tris[hit].n[1], tris[hit].n[2]};
+                    if (dot3(n, pd) > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+                    const double X[3] = {po[0] + thit * pd[0], po[1] + thit * pd[1], po[2] + thit * pd[2]};
+                    if (prim < 0) {      // nothing nearer than the light sample: radiance * brdf * geometry term * area, :53-61
+                        const lt_point_light lt = P.lights[P.light_choice[base + bounce]];
+                        const double cos_t = dot3(n, d);
+                        const double nsd[3] = {-d[0], -d[1], -d[2]};
+                        const double cos_p = dot3(lt.normal, nsd);
+                        const double geom = ::fabs(cos_t * cos_p) / (smag * smag);
+#pragma unroll
+                        for (int k = 0; k < 3; k++) L[k] += thr[k] * ((lt.radiance[k] * (M.diffuse[k] * inv_pi)) * geom * lt.total_area);
                     }
                     // indirect: cosine lobe, :63-80
                     double o4[4];
-                    cosine_hemi(n, d, r0, r1, o4);
+                    cosine_hemi<double, true>(n, pd, r0, r1, o4);
                     if (o4[3] == 0) { mark_unused(P.rand_0, base, bounce + 1, P.D); break; }
                     const double cos_theta = o4[0] * n[0] + o4[1] * n[1] + o4[2] * n[2];
 #pragma unroll
@@ -1748,9 +1821,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_surface(const Rend
                         o[k] = X[k] + eps * o4[k];
                         d[k] = o4[k];
                     }
-                } else if (M.is_mirror || M.transmission > 0.0) {           // :82-119
-                    specular_bounce(M, X, n, inside, r0, o, d);
-                } else break;                                               // :121-123
+                }
                 if (bounce > 5) {                                           // russian roulette, :126-132
                     const double rr = ::fmax(0.05, 1 - thr[1]);
                     if (r0 < rr) { mark_unused(P.rand_0, base, bounce + 1, P.D); break; }
@@ -1852,7 +1923,7 @@ __global__ void __launch_bounds__(kOldThreads) k_render_surface_old(const Render
                                 f_direct[0] = f_direct[1] = f_direct[2] = 0;
                             n_shadow++;
                             double o4[4];
-                            cosine_hemi(n, d, r0, r1, o4);
+                            cosine_hemi<double, true>(n, d, r0, r1, o4);
                             if (o4[3] == 0) { mark_unused(P.rand_0, base, f_bounce + 1, P.D); done = true; }
                             else {
                                 const double cos_theta = o4[0] * n[0] + o4[1] * n[1] + o4[2] * n[2];
