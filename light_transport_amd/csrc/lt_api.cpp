@@ -127,7 +127,7 @@ struct lt_ctx {
     // march grid (meshes whose f64 tables exceed the LDS budget): cell records, candidate lists, scratch of the builder
     DevBuf d_mcell, d_mlist, d_mcoarse, d_links;      // d_links: front-to-back threading of the BVH (bvh_octant_links)
     MarchGrid mgrid;
-    bool have_march = false;
+    bool have_march = false, have_links = false;
     size_t march_entries = 0;
     LogLane lanes[kMaxLanes];
     // hot-tile form of the two-pass partition (LogReduceParams::dmap): the map is made once per scene from the tile
@@ -177,6 +177,32 @@ struct lt_ctx {
     size_t n_vox() const { return (size_t)nx * (size_t)ny * (size_t)nz; }
     void scene_changed() { rec_per_photon = 0.0; for (double& a : auto_ms_per_photon) a = 0.0; for (uint64_t& a : auto_photons) a = 0; auto_pending = -1; dmap_valid = tile_cnt_ready = false; }
 };
+
+// Front-to-back threading of a flattened pre-order BVH for each of the 8 sign patterns of a ray direction (bit k set: the
+// direction is negative on axis k): first[i] = the child of interior node i that lies on the ray's side of the split plane --
+// the second child if the direction is negative on the node's axis, else the first (S/bvh_new.py:455-458) -- and after[i] = the
+// node the search goes to once the subtree of i is done (n = finished).  Layout [pattern][first | after][node], int16.
+static bool bvh_octant_links(const std::vector<lt_bvh_node>& nd, std::vector<int16_t>& out)
+{
+    const int n = (int)nd.size();
+    if (n <= 0 || n > 32767) return false;
+    out.assign((size_t)16 * n, (int16_t)n);
+    for (int oct = 0; oct < 8; oct++) {
+        int16_t* first = &out[(size_t)oct * 2 * n]; int16_t* after = first + n;
+        std::vector<std::pair<int, int>> todo{{0, n}};     // (node, where to go after its subtree)
+        while (!todo.empty()) {
+            const auto [i, a] = todo.back(); todo.pop_back();
+            after[i] = (int16_t)a;
+            if (nd[(size_t)i].n_prims > 0) continue;
+            const int c0 = i + 1, c1 = nd[(size_t)i].offset;
+            const bool neg = (oct >> nd[(size_t)i].axis) & 1;
+            const int near_ = neg ? c1 : c0, far_ = neg ? c0 : c1;
+            first[i] = (int16_t)near_;
+            todo.emplace_back(near_, far_); todo.emplace_back(far_, a);
+        }
+    }
+    return true;
+}
 
 #define CHECK_CTX(c) do { if (!(c)) return LT_E_INVALID; } while (0)
 #define HIP_TRY(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (c)->hip(e_, #call); } while (0)
@@ -421,6 +447,7 @@ int upload_tables(lt_ctx* c)
     std::vector<IfD<double>> i64; std::vector<IfD<float>> i32;
     std::vector<TriD<double>> t64; std::vector<TriD<float>> t32;
     std::vector<NodeD<double>> n64; std::vector<NodeD<float>> n32;
+    std::vector<int16_t> links16;
     fill_media(c->media, c->quantity, m64); fill_media(c->media, c->quantity, m32);
     if ((rc = upload(c, c->d_media[0], m64))) return rc;
     if ((rc = upload(c, c->d_media[1], m32))) return rc;
@@ -449,6 +476,8 @@ int upload_tables(lt_ctx* c)
         if ((rc = upload(c, c->d_tris[1], t32))) return rc;
         if ((rc = upload(c, c->d_nodes[0], n64))) return rc;
         if ((rc = upload(c, c->d_nodes[1], n32))) return rc;
+        c->have_links = bvh_octant_links(c->nodes, links16);
+        if (c->have_links && (rc = upload(c, c->d_links, links16))) return rc;
         // Which acceleration data the walks of this mesh use: tables within the LDS budget -> clearance grid with
         // near-triangle lists + BVH in LDS (GEOM 1); beyond it -> march grid (GEOM 2).  The f32 tables are about half the
         // size of the f64 ones, so a mesh may need both.
@@ -1202,7 +1231,7 @@ int lt_launch(lt_ctx* c, uint64_t n_photons, uint64_t photon_offset, uint64_t se
     P.n_photons = n_photons; P.photon_offset = photon_offset; P.seed = seed;
     const int pi = v.f32 ? 1 : 0;
     P.media = c->d_media[pi].p; P.zb = c->d_zb[pi].p; P.ifaces = c->d_if[pi].p; P.layer_medium = (const int32_t*)c->d_lm.p;
-    P.tris = c->d_tris[pi].p; P.nodes = c->d_nodes[pi].p;
+    P.tris = c->d_tris[pi].p; P.nodes = c->d_nodes[pi].p; P.links = c->have_mesh && c->have_links ? (const int16_t*)c->d_links.p : nullptr;
     P.n_media = n_media;
     P.n_layers = c->have_layers ? (int)c->layer_medium.size() : 0;
     P.n_tris = c->have_mesh ? (int)c->med_front.size() : 0;
@@ -1576,15 +1605,10 @@ int stage_in(lt_ctx* c, DevBuf& b, const void* h, size_t bytes)
 }
 }  // namespace
 
-static bool bvh_octant_links(const std::vector<lt_bvh_node>& nd, std::vector<int16_t>& out);
 // the link tables of the ctx mesh on the device (rebuilt per call: a few KB; the mesh may have changed)
-static int upload_links(lt_ctx* c)
+static int upload_links(lt_ctx* c)      // (upload_tables has put them on the device with the mesh)
 {
-    std::vector<int16_t> links;
-    if (!bvh_octant_links(c->nodes, links)) return c->fail(LT_E_UNSUPPORTED, "BVH of %zu nodes: the front-to-back order tables hold 16-bit links", c->nodes.size());
-    HIP_TRY(c, c->d_links.ensure(links.size() * sizeof(int16_t) + 4));
-    HIP_TRY(c, hipMemcpyAsync(c->d_links.p, links.data(), links.size() * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));      // (the staging vector dies here)
+    if (!c->have_links) return c->fail(LT_E_UNSUPPORTED, "BVH of %zu nodes: the front-to-back order tables hold 16-bit links", c->nodes.size());
     return LT_OK;
 }
 
@@ -1738,32 +1762,6 @@ int lt_set_lights(lt_ctx* c, const lt_point_light* lights, int n)
     if (!lights || n <= 0) return c->fail(LT_E_INVALID, "lt_set_lights: need at least one light sample");
     c->lights.assign(lights, lights + n);
     return LT_OK;
-}
-
-// Front-to-back threading of a flattened pre-order BVH for each of the 8 sign patterns of a ray direction (bit k set: the
-// direction is negative on axis k): first[i] = the child of interior node i that lies on the ray's side of the split plane --
-// the second child if the direction is negative on the node's axis, else the first (S/bvh_new.py:455-458) -- and after[i] = the
-// node the search goes to once the subtree of i is done (n = finished).  Layout [pattern][first | after][node], int16.
-static bool bvh_octant_links(const std::vector<lt_bvh_node>& nd, std::vector<int16_t>& out)
-{
-    const int n = (int)nd.size();
-    if (n <= 0 || n > 32767) return false;
-    out.assign((size_t)16 * n, (int16_t)n);
-    for (int oct = 0; oct < 8; oct++) {
-        int16_t* first = &out[(size_t)oct * 2 * n]; int16_t* after = first + n;
-        std::vector<std::pair<int, int>> todo{{0, n}};     // (node, where to go after its subtree)
-        while (!todo.empty()) {
-            const auto [i, a] = todo.back(); todo.pop_back();
-            after[i] = (int16_t)a;
-            if (nd[(size_t)i].n_prims > 0) continue;
-            const int c0 = i + 1, c1 = nd[(size_t)i].offset;
-            const bool neg = (oct >> nd[(size_t)i].axis) & 1;
-            const int near_ = neg ? c1 : c0, far_ = neg ? c0 : c1;
-            first[i] = (int16_t)near_;
-            todo.emplace_back(near_, far_); todo.emplace_back(far_, a);
-        }
-    }
-    return true;
 }
 
 static int render_impl(lt_ctx* c, int variant, int choices, int width, int height, int samples, int max_depth,

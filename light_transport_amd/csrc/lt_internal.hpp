@@ -119,6 +119,7 @@ struct WalkParams {
     const int32_t* layer_medium;
     const void* tris;
     const void* nodes;
+    const int16_t* links;       // [8][2][n_nodes] front-to-back threading of the BVH (bvh_octant_links); null beyond 32767 nodes
     int n_media, n_layers, n_tris, n_nodes;
     double n_above, n_below;
     // voxel grid

@@ -416,6 +416,15 @@ LT_DEV void nearest_bvh_ordered(const TriD<R>* tris, const NodeD<R>* nodes, int 
     prim = bi; t_out = bi >= 0 ? bt : Mx<R>::inf();
 }
 LT_DEV int ray_octant(const double* d) { return (d[0] < 0 ? 1 : 0) | (d[1] < 0 ? 2 : 0) | (d[2] < 0 ? 4 : 0); }
+LT_DEV int ray_octant(const float* d) { return (d[0] < 0 ? 1 : 0) | (d[1] < 0 ? 2 : 0) | (d[2] < 0 ? 4 : 0); }
+// the walks' BVH search: front to back where the mesh has link tables (every mesh of <= 32767 nodes), in storage order otherwise
+template <typename R>
+LT_DEV void nearest_bvh_walk(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes, const int16_t* links, const R* o,
+                             const R* d, R tmax, int& prim, R& t_out)
+{
+    if (links) nearest_bvh_ordered(tris, nodes, n_nodes, links + ray_octant(d) * 2 * n_nodes, o, d, tmax, prim, t_out);
+    else nearest_bvh(tris, nodes, n_nodes, o, d, tmax, prim, t_out);
+}
 
 template <typename R>
 LT_DEV void nearest_brute(const TriD<R>* tris, int n_tris, const R* o, const R* d, R tmax,
@@ -430,7 +439,7 @@ LT_DEV void nearest_brute(const TriD<R>* tris, int n_tris, const R* o, const R* 
 // clearance record (WalkParams::clear): they are tested directly -- same tri_hit, same nearest / tie rule, hence the
 // same answer as the BVH walk, which is left to the hops that reach farther.
 template <typename R>
-LT_DEV void nearest_listed(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes, const uint4 rec, const R* o,
+LT_DEV void nearest_listed(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes, const int16_t* links, const uint4 rec, const R* o,
                            const R* d, R tmax, int& prim, R& t_out)
 {
     const float c2 = (float)__builtin_bit_cast(_Float16, (unsigned short)(rec.y & 0xffffu));
@@ -727,14 +736,14 @@ LT_DEV void march_drain(const TriD<R>* tris, const MarchGrid& G, MarchWave<R>* W
 
 // a finished query's answer (the lane's slot, or the BVH for the queries the grid could not take)
 template <typename R>
-LT_DEV void march_result(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes, MarchWave<R>* W, bool use_bvh, R px, R py, R pz,
+LT_DEV void march_result(const TriD<R>* tris, const NodeD<R>* nodes, int n_nodes, const int16_t* links, MarchWave<R>* W, bool use_bvh, R px, R py, R pz,
                          R ux, R uy, R uz, R tmax, int& prim, R& t_out)
 {
     const unsigned lane = threadIdx.x & 63u;
     prim = -1; t_out = Mx<R>::inf();
     if (use_bvh) {
         const R o[3] = {px, py, pz}, d[3] = {ux, uy, uz};
-        nearest_bvh(tris, nodes, n_nodes, o, d, tmax, prim, t_out);
+        nearest_bvh_walk(tris, nodes, n_nodes, links, o, d, tmax, prim, t_out);
     } else {
         const typename MarchBits<R>::type b = W->slot_t[lane];
         if (b < march_bits(tmax)) { prim = (int)W->slot_i[lane]; t_out = march_unbits(b); }
@@ -755,7 +764,7 @@ LT_DEV void march_service(const TriD<R>* tris, const NodeD<R>* nodes, int n_node
         if (__any(marching)) full = march_round(G, W, marching, heavy, dirty, tcur, qn);
         if (qn > 0 && (full || qn >= 64u || !__any(marching))) march_drain(tris, G, W, qn);
     }
-    if (want) march_result(tris, nodes, n_nodes, W, outside || heavy, px, py, pz, ux, uy, uz, tmax, prim, t_out);
+    if (want) march_result(tris, nodes, n_nodes, (const int16_t*)nullptr, W, outside || heavy, px, py, pz, ux, uy, uz, tmax, prim, t_out);
     else { prim = -1; t_out = Mx<R>::inf(); }
 }
 
@@ -982,7 +991,7 @@ template <int TALLY> LT_DEV void tally_add(void* grid, unsigned idx, typename Ta
 LT_DEV size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 template <typename R> struct LdsLayout {
-    size_t off_cnt, off_frame, off_media, off_zb, off_if, off_lm, off_tris, off_nodes, off_hist, off_march, total;
+    size_t off_cnt, off_frame, off_media, off_zb, off_if, off_lm, off_tris, off_nodes, off_links, off_hist, off_march, total;
     __host__ __device__ LdsLayout(int n_media, int n_layers, int n_tris, int n_nodes, unsigned n_hist = 0, size_t march_bytes = 0)
     {
         auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -995,6 +1004,7 @@ template <typename R> struct LdsLayout {
         off_lm = o;    o = al(o + (size_t)(n_layers > 0 ? n_layers : 1) * sizeof(int32_t));
         off_tris = o;  o = al(o + (size_t)n_tris * sizeof(TriD<R>));
         off_nodes = o; o = al(o + (size_t)n_nodes * sizeof(NodeD<R>));
+        off_links = o; o = al(o + (size_t)n_nodes * 16 * sizeof(int16_t));      // front-to-back link tables (8 patterns x first | after)
         off_hist = o;  o = al(o + (size_t)n_hist * sizeof(uint32_t));
         off_march = o; o = al(o + march_bytes);
         total = o;
