@@ -235,7 +235,8 @@ def self_launch(n, argv):
 
 def measure_extra(name, make_ctx, args, cpu_seconds):
     """One more BASELINE config after the headline's timed region (single GPU): flat keys for the JSON line.
-    (a) throughput: two contexts take whole jobs in turn, walks at half of the resident workgroups each (the two_jobs regime);
+    (a) throughput: two or three contexts take whole jobs in turn (the two_jobs / walk_train / three_jobs regimes of the
+        headline, each measured; the fastest is the figure);
     (b) latency: ONE lt_launch alone, library defaults (what a trace_photons caller gets);
     (c) its kernels on one lane, nothing beside them (tail split off: the per-kernel figures);
     (d) the CPU oracle on the same workload, bounded sample."""
@@ -244,30 +245,32 @@ def measure_extra(name, make_ctx, args, cpu_seconds):
     half = 3 if args.f32_walk else 2
     cs = []
     try:
-        for _ in range(2):
+        def add_ctx():
             c = make_ctx()
             configure(c, wl, args.tally)
             c.set_tally_mode(args.tally_mode); c.set_overlap(1); c.set_launch_config(half, 256)
             if args.tally_mode != "atomic":
                 c.reserve_log(n)
             cs.append(c)
+        for _ in range(2):
+            add_ctx()
 
         def jobs(k, seed0):
-            steps = 0
+            d, steps = len(cs), 0
             for c in cs:
                 c.sync()
             t0 = time.perf_counter()
             for j in range(k):
-                c = cs[j % 2]
-                if j >= 2:
+                c = cs[j % d]
+                if j >= d:
                     c.sync(); steps += c.read_counters()["steps"]
                 c.zero_tally(); c.launch(n, seed=seed0 + j, f32_walk=args.f32_walk)
-            for j in range(max(0, k - 2), k):
-                c = cs[j % 2]
+            for j in range(max(0, k - d), k):
+                c = cs[j % d]
                 c.sync(); steps += c.read_counters()["steps"]
             return (time.perf_counter() - t0) / k * 1e3, steps / k
-        # two ways of keeping two jobs in flight (bench.py's two_jobs and walk_train regimes at depth 2); the faster is reported,
-        # both are kept
+        # ways of keeping jobs in flight (bench.py's two_jobs, walk_train at depth 2 and -- where three deposit logs fit, the
+        # 256^3 grids -- three_jobs); the fastest is reported, all are kept
         jobs(4, 700)                      # pilot batch of the scene, log sizing, warm-up
         ms, steps = jobs(8, 710)
         regime, both = "two_jobs", {name + "_two_jobs_ms": ms}
@@ -280,7 +283,15 @@ def measure_extra(name, make_ctx, args, cpu_seconds):
             if ms_t < ms:
                 ms, steps, regime = ms_t, steps_t, "walk_train"
             for c in cs:
-                c.set_tuning("serial_walks", -1)
+                c.set_tuning("serial_walks", -1); c.set_launch_config(half, 256)
+        if wl["grid"] <= 256:
+            add_ctx()
+            jobs(6, 760)
+            ms_3, steps_3 = jobs(12, 770)
+            both[name + "_three_jobs_ms"] = ms_3
+            if ms_3 < ms:
+                ms, steps, regime = ms_3, steps_3, "three_jobs"
+            cs.pop().close()
         out = {name + "_ms": ms, name + "_steps_per_s": steps / (ms * 1e-3), name + "_photons_per_s": n / (ms * 1e-3),
                name + "_frac": steps * BYTES_PER_STEP[args.tally] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, name + "_regime": regime,
                name + "_steps_per_job": steps}

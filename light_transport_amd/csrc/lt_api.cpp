@@ -141,7 +141,7 @@ struct lt_ctx {
     struct Knobs {
         long query_min = -1, log_bits2 = -1, log_hot = -1, overlap_walk_bpc = -1, diag_no_tally = -1, log_timing = -1,
              march_cells = -1, march_scale_milli = -1, no_march = -1, no_clearance = -1, no_near_lists = -1,
-             clearance_cells = -1, march_info = -1, force_march = -1, tail_split = -1, part_alone = -1, serial_walks = -1;
+             clearance_cells = -1, march_info = -1, force_march = -1, tail_split = -1, part_alone = -1, serial_walks = -1, part_lds = -1;
         std::string overlap_pattern;      // LT_OVERLAP_PATTERN (relative sub-batch sizes; tools/pattern_ab.py)
     } knob;
     long* knob_by_name(const char* key)
@@ -151,7 +151,7 @@ struct lt_ctx {
             {"overlap_walk_bpc", &Knobs::overlap_walk_bpc}, {"diag_no_tally", &Knobs::diag_no_tally}, {"log_timing", &Knobs::log_timing},
             {"march_cells", &Knobs::march_cells}, {"march_scale_milli", &Knobs::march_scale_milli}, {"no_march", &Knobs::no_march},
             {"no_clearance", &Knobs::no_clearance}, {"no_near_lists", &Knobs::no_near_lists}, {"clearance_cells", &Knobs::clearance_cells},
-            {"march_info", &Knobs::march_info}, {"force_march", &Knobs::force_march}, {"tail_split", &Knobs::tail_split}, {"part_alone", &Knobs::part_alone}, {"serial_walks", &Knobs::serial_walks}};
+            {"march_info", &Knobs::march_info}, {"force_march", &Knobs::force_march}, {"tail_split", &Knobs::tail_split}, {"part_alone", &Knobs::part_alone}, {"serial_walks", &Knobs::serial_walks}, {"part_lds", &Knobs::part_lds}};
         for (const auto& t : tab) if (std::strcmp(key, t.k) == 0) return &(knob.*(t.m));
         return nullptr;
     }
@@ -860,6 +860,7 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         // part_alone = 0 / 1 pins the build for A/B runs)
         L.alone = (plan.lanes == 1 && c->blocks_per_cu == 0 && !split) ? 1 : 0;
         if (c->knob.part_alone == 0 || c->knob.part_alone == 1) L.alone = (int)c->knob.part_alone;
+        L.lds_part = c->knob.part_lds > 0 ? (c->knob.part_lds > 1 ? 2 : 1) : 0;
         Variant vw = R.v;
         if (split) {
             const size_t cap = (size_t)cfg.blocks * (size_t)(cfg.threads / 64) * kDumpPoolLanes;      // every wave hands over at most that many
@@ -974,7 +975,7 @@ int lt_create(lt_ctx** out, int device_id)
     c->device = device_id;
     {   // the one place the environment is read: LT_QUERY_MIN, LT_LOG_HOT, ... seed the knobs of lt_set_tuning
         static const char* const names[] = {"query_min", "log_bits2", "log_hot", "overlap_walk_bpc", "diag_no_tally", "log_timing", "march_cells",
-                                            "march_scale_milli", "no_march", "no_clearance", "no_near_lists", "clearance_cells", "march_info", "force_march", "tail_split", "part_alone", "serial_walks"};
+                                            "march_scale_milli", "no_march", "no_clearance", "no_near_lists", "clearance_cells", "march_info", "force_march", "tail_split", "part_alone", "serial_walks", "part_lds"};
         for (const char* k : names) {
             std::string name = "LT_";
             for (const char* q = k; *q; q++) name += (char)std::toupper((unsigned char)*q);

@@ -266,6 +266,8 @@ struct LogReduceParams {
                                                // the partition may take the register budget that leaves no room for a co-running walk
     int flush_atomic;                          // every tile adds to the grid with atomics (another lane of the same
                                                // launch may be updating it at the same time)
+    int lds_part;                              // one-pass grids: the LDS-staged partition (k_log_part_lds: one workgroup per CU, the next
+                                               // item arrives by LDS-DMA while this one is sorted) instead of k_log_part
 };
 hipError_t launch_log_scan_bins(const LogReduceParams& L, hipStream_t s);
 hipError_t launch_log_count1(const LogReduceParams& L, hipStream_t s);      // hot-tile form: pass-1 digit histogram from the log

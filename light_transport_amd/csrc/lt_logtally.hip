@@ -388,6 +388,161 @@ __global__ void __launch_bounds__(kPartThreads, ALONE ? LT_PART_WAVES_ALONE : LT
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The same counting sort for ONE workgroup per CU (one-pass grids): k_log_part keeps an item in registers and needs two
+// workgroups per CU (2 x 8 waves, 2 x 128 VGPRs per SIMD lane) so that one's loads fly under the other's LDS work -- at one
+// workgroup per CU it is latency-bound (10 -> 25-34 ms), which is what the walk train's free register quarter offers it.  Here
+// the NEXT item -- 16 KiB of indices and 32 KiB of values -- arrives by LDS-DMA (global_load_lds_dwordx4: no registers, the
+// image is lane-linear, i.e. a plain copy of the item) into a second staging buffer while this item is ranked, scanned and
+// scattered from the first: 48 KiB in flight per CU for the whole length of an item.  LDS: 2 x 48 KiB staging + 48 KiB sorted
+// copy + 4 KiB of tables = 148 KiB.  Barriers between the DMA's issue and the point its data is needed are raw s_barrier with
+// an lgkmcnt-only wait (a __syncthreads() would drain the DMA: it waits vmcnt(0)).
+#define LT_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <typename TV>
+__global__ void __launch_bounds__(kPartThreads, 8) k_log_part_lds(LogReduceParams L)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    uint32_t* sK = reinterpret_cast<uint32_t*>(s_dyn);                                                           // [2][kPartItem] staged indices
+    TV* sV = reinterpret_cast<TV*>(s_dyn + 2 * (size_t)kPartItem * sizeof(uint32_t));                             // [2][kPartItem] staged values
+    TV* oV = sV + 2 * (size_t)kPartItem;                                                                          // [kPartItem] digit-sorted values
+    uint32_t* oK = reinterpret_cast<uint32_t*>(oV + kPartItem);                                                   // [kPartItem] digit-sorted indices
+    uint32_t* s_a = oK + kPartItem;                                                                               // [kMaxBins + 2] counts -> offsets -> global bases
+    __shared__ uint32_t s_wsum[kPartThreads / 64];
+    const uint32_t nb = L.n_tiles;
+    const uint32_t n_units = claimed_chunks(L);
+    const uint32_t* in_idx = L.log_idx;
+    const TV* in_val = reinterpret_cast<const TV*>(L.log_val);
+    uint32_t* out_idx = L.tmp_idx;
+    TV* out_val = reinterpret_cast<TV*>(L.tmp_val);
+
+    // the items of this workgroup, in order: (first record, records) of every non-empty 4096-record half of its chunks
+    uint32_t unit = blockIdx.x, sub = 0, fill = unit < n_units ? L.log_fill[unit] : 0u;
+    auto settle = [&]() -> bool {      // move (unit, sub) to the next non-empty item at or after the current position
+        for (;;) {
+            if (unit >= n_units) return false;
+            if (sub < kItemsPerChunk && fill > sub * kPartItem) return true;
+            unit += gridDim.x; sub = 0; fill = unit < n_units ? L.log_fill[unit] : 0u;
+        }
+    };
+    // One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS[dst + lane * 16] (M0 = dst, wave-uniform).
+    // Written as asm so that the compiler's wait-count pass does not know about it: through the builtin it drains the DMA
+    // (s_waitcnt vmcnt(0)) in front of the first LDS read that follows, i.e. at once.  The waits are placed by hand below;
+    // the compiler's own counted waits can only become stricter by operations it does not see.
+    auto glds16 = [](const void* gsrc, uint32_t lds_dst) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    };
+    auto lds_addr = [](const void* p_) -> uint32_t {
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(const __attribute__((address_space(3))) void*)p_);
+    };
+    auto stage = [&](uint32_t lo, uint32_t buf) {      // LDS-DMA of the item that starts at record lo into staging buffer buf
+        const uint32_t tid_ = threadIdx.x, w = tid_ >> 6, l = tid_ & 63u;
+#pragma unroll
+        for (uint32_t j = 0; j < 2; j++)
+            glds16(in_idx + lo + (w * 2 + j) * 256 + l * 4, lds_addr(sK + buf * kPartItem + (w * 2 + j) * 256));
+        constexpr uint32_t per = 16 / sizeof(TV), nj = kPartItem * sizeof(TV) / (8 * 1024);      // values per lane per instruction; instructions per wave
+#pragma unroll
+        for (uint32_t j = 0; j < nj; j++)
+            glds16(in_val + lo + (w * nj + j) * (64 * per) + l * per, lds_addr(sV + buf * kPartItem + (w * nj + j) * (64 * per)));
+    };
+    if (!settle()) return;
+    uint32_t buf = 0;
+    stage(unit * kLogChunk + sub * kPartItem, buf);
+    for (;;) {
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));       // (lane-derived addresses and masks recomputed per item, not hoisted: see k_log_part)
+        const int lane = (int)(tid & 63u), wave = (int)(tid >> 6);
+        const uint32_t cur_unit = unit, n = fill - sub * kPartItem < kPartItem ? fill - sub * kPartItem : kPartItem;
+        sub++;
+        const bool have_next = settle();
+        uint32_t* cursor = L.cursor1 + (cur_unit & (kLogGroups - 1));
+        const uint32_t* kb = sK + buf * kPartItem;
+        const TV* vb = sV + buf * kPartItem;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this item's DMA (and the previous item's stores) are done ...
+        LT_LDS_BARRIER();                                     // ... in every wave; the other staging buffer is free
+        if (have_next) stage(unit * kLogChunk + sub * kPartItem, buf ^ 1u);
+        for (uint32_t d = tid; d < nb + 2; d += kPartThreads) s_a[d] = 0;
+        LT_LDS_BARRIER();
+        // ---- rank inside the digit
+        uint32_t key[kPerThread], ret2[kPerThread / 2];
+#pragma unroll
+        for (int g = 0; g < kPerThread / 4; g++) {
+            const uint4 q = *reinterpret_cast<const uint4*>(kb + (uint32_t)g * (kPartThreads * 4) + tid * 4);
+            key[4 * g] = q.x; key[4 * g + 1] = q.y; key[4 * g + 2] = q.z; key[4 * g + 3] = q.w;
+        }
+#pragma unroll
+        for (int r = 0; r < kPerThread; r++) {
+            const uint32_t k = (uint32_t)(r >> 2) * (kPartThreads * 4) + tid * 4 + (r & 3);
+            const uint32_t rk = k < n ? atomicAdd(&s_a[tile_of(key[r])], 1u) : 0u;
+            if (r & 1) ret2[r >> 1] |= rk << 16; else ret2[r >> 1] = rk;
+        }
+        LT_LDS_BARRIER();
+        // ---- space for every non-empty digit (one returning global atomic each), exclusive prefix over the digits
+        uint32_t c0 = 0, c1 = 0, g0 = 0, g1 = 0, incl;
+        {
+            const uint32_t d = 2 * tid;
+            if (d < nb) { const uint2 cc = *reinterpret_cast<const uint2*>(&s_a[d]); c0 = cc.x; c1 = d + 1 < nb ? cc.y : 0; }
+            if (c0) g0 = atomicAdd(&cursor[d * kLogGroups], c0);
+            if (c1) g1 = atomicAdd(&cursor[(d + 1) * kLogGroups], c1);
+            incl = c0 + c1;
+#pragma unroll
+            for (int off2 = 1; off2 < 64; off2 <<= 1) { const uint32_t o = __shfl_up(incl, off2, 64); if (lane >= off2) incl += o; }
+            if (lane == 63) s_wsum[wave] = incl;
+        }
+        LT_LDS_BARRIER();
+        uint32_t ex = 0;
+        {
+            uint32_t before = 0;
+#pragma unroll
+            for (int w = 0; w < kPartThreads / 64; w++) before += w < wave ? s_wsum[w] : 0;
+            ex = before + incl - (c0 + c1);
+            const uint32_t d = 2 * tid;
+            if (d < nb) *reinterpret_cast<uint2*>(&s_a[d]) = make_uint2(ex, ex + c0);
+        }
+        LT_LDS_BARRIER();
+        // ---- digit-sorted copy in LDS (values straight from the staging buffer)
+#pragma unroll
+        for (int g = 0; g < kPerThread / 4; g++) {
+            const Quad<TV> v = *reinterpret_cast<const Quad<TV>*>(vb + (uint32_t)g * (kPartThreads * 4) + tid * 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = 4 * g + j;
+                const uint32_t k = (uint32_t)g * (kPartThreads * 4) + tid * 4 + (uint32_t)j;
+                if (k < n) {
+                    const uint32_t p = s_a[tile_of(key[r])] + ((r & 1) ? ret2[r >> 1] >> 16 : (ret2[r >> 1] & 0xffffu));
+                    oK[p] = key[r]; oV[p] = v.v[j];
+                }
+            }
+        }
+        // (the bases are "used" on every path: were their only use under if (c0) / if (c1), the path "atomic issued, use skipped"
+        //  would exist for the compiler and it would wait for them -- vmcnt(0), the DMA with them -- before the next item's atomics)
+        asm volatile("" :: "v"(g0), "v"(g1));
+        LT_LDS_BARRIER();       // every lane has read its digits' offsets: the global bases take their place
+        {
+            const uint32_t d = 2 * tid;
+            if (c0) s_a[d] = g0 - ex;
+            if (c1) s_a[d + 1] = g1 - (ex + c0);
+        }
+        LT_LDS_BARRIER();
+        // ---- write out: consecutive sorted positions of one digit are consecutive in memory; the final pass keeps the
+        //      14-bit position inside the tile only (2 bytes)
+#pragma unroll
+        for (int i = 0; i < kPerThread; i++) {
+            const uint32_t p = tid + (uint32_t)i * kPartThreads;
+            if (p < n) {
+                const uint32_t kk = oK[p];
+                const uint32_t dst = s_a[tile_of(kk)] + p;
+                reinterpret_cast<uint16_t*>(out_idx)[dst] = (uint16_t)(kk & (kTileSize - 1));
+                out_val[dst] = oV[p];
+            }
+        }
+        if (!have_next) break;
+        buf ^= 1u;
+        // (the barrier at the top of the next item separates these LDS reads from the next item's writes)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Two-pass form: records per tile, counted from pass 1's output (indices only).  A workgroup takes up to kCountGroup
 // consecutive pass-2 items of ONE level-1 bin, counts their tiles in an LDS histogram of <= 128 entries and flushes it
 // with one global atomic per non-empty tile.
@@ -662,8 +817,29 @@ template <int PASS, bool HOT> static hipError_t launch_part(const LogReduceParam
     if (L.tally == LT_TALLY_F64) return launch_part_t<double, PASS, HOT>(L, s);
     return launch_part_t<unsigned long long, PASS, HOT>(L, s);
 }
+template <typename TV> static hipError_t launch_part_lds_t(const LogReduceParams& L, hipStream_t s)
+{
+    const size_t lds = (size_t)kPartItem * (3 * sizeof(TV) + 3 * sizeof(uint32_t)) + (size_t)(kMaxBins + 2) * sizeof(uint32_t);
+    const void* fn = reinterpret_cast<const void*>(&k_log_part_lds<TV>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    static BlockCache blocks{};
+    unsigned grid = persistent_blocks(blocks, fn, kPartThreads, lds) / kLogGroups * kLogGroups;      // a workgroup serves one cursor group
+    if (grid < kLogGroups) grid = kLogGroups;
+    hipLaunchKernelGGL((k_log_part_lds<TV>), dim3(grid), dim3(kPartThreads), lds, s, L);
+    return hipGetLastError();
+}
+
 hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s)
 {
+    if (L.lds_part) {      // lt_set_tuning "part_lds": 1 = where it applies (one-pass grids), 2 = or fail (tests: proves the route)
+        if (!L.dmap && L.bits2 == 0 && L.n_tiles <= (uint32_t)kMaxBins) {
+            if (L.tally == LT_TALLY_F32) return launch_part_lds_t<float>(L, s);
+            if (L.tally == LT_TALLY_F64) return launch_part_lds_t<double>(L, s);
+            return launch_part_lds_t<unsigned long long>(L, s);
+        }
+        if (L.lds_part == 2) return hipErrorInvalidValue;
+    }
     if (L.dmap) {
         if (L.bits2 == 0 || L.n_tiles > kMaxHotTiles) return hipErrorInvalidValue;
         return launch_part<1, true>(L, s);

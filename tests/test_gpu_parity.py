@@ -1065,6 +1065,48 @@ def test_config5_geometry_512_cubed(ctx):
     ctx.set_grid((8, 8, 8), (0, 0, 0), (1, 1, 1), "f64")     # release the 1 GiB grid of the session ctx
 
 
+def test_lds_staged_partition_equals_the_register_staged_one(ctx):
+    """lt_set_tuning "part_lds" (k_log_part_lds: the next item arrives by LDS-DMA while this one is sorted) against the default
+    partition and the atomic tally: bit-identical fixed-point grids -- ample log, a log budget that forces several batches
+    (short last chunks, chunks nobody claimed), two lanes, a grid that is not a multiple of the tile, a mesh scene, and a
+    launch so small that most items are ragged.  part_lds = 2 makes lt_launch FAIL where that partition cannot run, so a launch
+    that succeeds has taken it; the two-pass grid checks that the failure is real (the knob reaches the launcher)."""
+    import light_transport_amd as lt
+    odd = S.Problem([(0.1, 10.0, 0.9, 1.0)], (100, 70, 33), (-5.0, -3.5, 0.0), (0.1,) * 3,
+                    layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))
+    big = S.Problem([(0.1, 10.0, 0.9, 1.0)], (300, 300, 200), (-15.0, -15.0, 0.0), (0.1,) * 3,
+                    layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))   # 1300 tiles: two-pass partition
+    for prob, n in ((S.slab(), 300000), (odd, 300000), (S.cornell(64), 100000), (S.slab(), 700)):
+        prob.apply(ctx, "u64fx"); ctx.set_tally_mode("atomic"); ctx.set_overlap(1)
+        ctx.launch(n, seed=11); ctx.sync()
+        ref, cref = ctx.read_grid_raw(), ctx.read_counters()
+        for log_bytes, lanes in ((8 << 30, 1), (48 << 20, 1), (8 << 30, 2), (48 << 20, 2)):
+            for part_lds in (0, 2):
+                with ctx.tuning(part_lds=part_lds):
+                    prob.apply(ctx, "u64fx"); ctx.set_tally_mode("log", log_bytes); ctx.set_overlap(lanes)
+                    ctx.launch(n, seed=11); ctx.sync()
+                    g, c, info = ctx.read_grid_raw(), ctx.read_counters(), ctx.last_log_info()
+                assert info is not None and info["records"] > 0, (log_bytes, lanes, part_lds)
+                assert np.array_equal(g, ref), (n, log_bytes, lanes, part_lds)
+                assert c["steps"] == cref["steps"]
+    # float tallies: equal up to the order of the adds inside a tile
+    S.slab().apply(ctx, "f64"); ctx.set_tally_mode("log"); ctx.set_overlap(1)
+    gs = []
+    for part_lds in (0, 2):
+        with ctx.tuning(part_lds=part_lds):
+            ctx.zero_tally(); ctx.launch(300000, seed=3); ctx.sync(); gs.append(ctx.read_grid_raw())
+    assert np.allclose(gs[0], gs[1], rtol=1e-11, atol=0) and gs[0].sum() > 0
+    c2 = lt.Context(0)
+    try:
+        with c2.tuning(part_lds=2):
+            big.apply(c2, "u64fx"); c2.set_tally_mode("log"); c2.set_overlap(1)
+            with pytest.raises(lt.LtError):
+                c2.launch(300000, seed=5); c2.sync()
+    finally:
+        c2.close()
+    ctx.set_overlap(0); ctx.set_tally_mode("auto")
+
+
 def test_tail_split_changes_nothing_but_the_route(ctx):
     """Slab walks in log mode end their walk kernel early and finish the last photons of every wave in a second kernel beside
     the log reduction (lt_walk_kernel.inc "Tail split").  Off (knob 0), default, and forced with thresholds 16 / 48 (a wave hands over when at
