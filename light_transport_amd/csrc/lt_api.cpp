@@ -860,7 +860,7 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         // part_alone = 0 / 1 pins the build for A/B runs)
         L.alone = (plan.lanes == 1 && c->blocks_per_cu == 0 && !split) ? 1 : 0;
         if (c->knob.part_alone == 0 || c->knob.part_alone == 1) L.alone = (int)c->knob.part_alone;
-        L.lds_part = c->knob.part_lds > 0 ? (c->knob.part_lds > 1 ? 2 : 1) : 0;
+        L.lds_part = c->knob.part_lds > 0 ? (int)(c->knob.part_lds & 7) : 0;
         Variant vw = R.v;
         if (split) {
             const size_t cap = (size_t)cfg.blocks * (size_t)(cfg.threads / 64) * kDumpPoolLanes;      // every wave hands over at most that many

@@ -388,21 +388,39 @@ __global__ void __launch_bounds__(kPartThreads, ALONE ? LT_PART_WAVES_ALONE : LT
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The same counting sort for ONE workgroup per CU (one-pass grids): k_log_part keeps an item in registers and needs two
-// workgroups per CU (2 x 8 waves, 2 x 128 VGPRs per SIMD lane) so that one's loads fly under the other's LDS work -- at one
-// workgroup per CU it is latency-bound (10 -> 25-34 ms), which is what the walk train's free register quarter offers it.  Here
-// the NEXT item -- 16 KiB of indices and 32 KiB of values -- arrives by LDS-DMA (global_load_lds_dwordx4: no registers, the
-// image is lane-linear, i.e. a plain copy of the item) into a second staging buffer while this item is ranked, scanned and
-// scattered from the first: 48 KiB in flight per CU for the whole length of an item.  LDS: 2 x 48 KiB staging + 48 KiB sorted
-// copy + 4 KiB of tables = 148 KiB.  Barriers between the DMA's issue and the point its data is needed are raw s_barrier with
-// an lgkmcnt-only wait (a __syncthreads() would drain the DMA: it waits vmcnt(0)).
+// The same counting sort for ONE workgroup per CU (one-pass grids; lt_set_tuning "part_lds").  k_log_part keeps an item in
+// registers and needs two workgroups per CU (2 x 8 waves, 2 x 128 VGPRs per SIMD lane) so that one's loads fly under the other's
+// LDS work -- at one workgroup per CU it is latency-bound (10 -> 25-34 ms), which is all the register quarter beside a walk
+// train offers it.  Here the NEXT item arrives by LDS-DMA (global_load_lds_dwordx4: no registers, the image is lane-linear,
+// i.e. a plain copy of the item) while this one is ranked, scanned and scattered: its 32 KiB of values into a second staging
+// buffer from the top of the item, its 16 KiB of indices into the ONE index buffer as soon as every wave holds this item's
+// indices in registers (after the ranking).  LDS: 16 + 2 x 32 KiB staging + 48 KiB sorted copy + 4 KiB of tables = 136 KiB,
+// which leaves three slab walk workgroups their 4.6 KiB each.  One vmcnt wait per item: where the cursor atomics' results are
+// needed -- the DMA was issued before them and vmcnt counts in order, so it has landed too; the item's own stores drain under
+// the next item's ranking.  Barriers are raw s_barrier with an lgkmcnt-only wait.  Measured (C2, 1.81e9 records): 10.5 ms
+// against k_log_part's 10.1 on an idle device (both ~3.8 TB/s: the bound is the scattered write-out, not latency -- 1024
+// lanes per workgroup change nothing, and the per-phase clocks of tools/part_phases.py are flat); beside a walk train it runs
+// at the walk's length (37-39 ms), and no jobs-in-flight regime gains from it -- hence a knob, not the default.
+#ifdef LT_PART_PROF      // measurement builds only (tools/build_variant.sh): clock sums per phase of k_log_part_lds, first wave of every workgroup
+__device__ unsigned long long g_part_phase[8];
+#define LT_PP_DECL unsigned long long pp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pp_t = __builtin_readcyclecounter()
+#define LT_PP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); pp_[i] += t_ - pp_t; pp_t = t_; } while (0)
+#define LT_PP_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_part_phase[i_], pp_[i_]); } while (0)
+#else
+#define LT_PP_DECL
+#define LT_PP(i)
+#define LT_PP_FLUSH
+#endif
 #define LT_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-template <typename TV>
-__global__ void __launch_bounds__(kPartThreads, 8) k_log_part_lds(LogReduceParams L)
+template <typename TV, int THREADS>
+__global__ void __launch_bounds__(THREADS, 8) k_log_part_lds(LogReduceParams L)
 {
+    constexpr int kPerThread = (int)kPartItem / THREADS;      // (shadows the register-staged kernel's: 8 at 512 lanes, 4 at 1024)
+    constexpr uint32_t kPartThreads = THREADS;
+    static_assert(kPerThread % 4 == 0 && 2 * THREADS >= kMaxBins, "a lane reads its records four at a time and owns two digits");
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    uint32_t* sK = reinterpret_cast<uint32_t*>(s_dyn);                                                           // [2][kPartItem] staged indices
-    TV* sV = reinterpret_cast<TV*>(s_dyn + 2 * (size_t)kPartItem * sizeof(uint32_t));                             // [2][kPartItem] staged values
+    uint32_t* sK = reinterpret_cast<uint32_t*>(s_dyn);                                                           // [kPartItem] staged indices (ONE buffer: in registers after the ranking's first read)
+    TV* sV = reinterpret_cast<TV*>(s_dyn + (size_t)kPartItem * sizeof(uint32_t));                                 // [2][kPartItem] staged values
     TV* oV = sV + 2 * (size_t)kPartItem;                                                                          // [kPartItem] digit-sorted values
     uint32_t* oK = reinterpret_cast<uint32_t*>(oV + kPartItem);                                                   // [kPartItem] digit-sorted indices
     uint32_t* s_a = oK + kPartItem;                                                                               // [kMaxBins + 2] counts -> offsets -> global bases
@@ -414,13 +432,22 @@ __global__ void __launch_bounds__(kPartThreads, 8) k_log_part_lds(LogReduceParam
     uint32_t* out_idx = L.tmp_idx;
     TV* out_val = reinterpret_cast<TV*>(L.tmp_val);
 
-    // the items of this workgroup, in order: (first record, records) of every non-empty 4096-record half of its chunks
-    uint32_t unit = blockIdx.x, sub = 0, fill = unit < n_units ? L.log_fill[unit] : 0u;
+    // the items of this workgroup, in order: (first record, records) of every non-empty 4096-record half of its chunks.  Chunk
+    // fills come through the SCALAR cache (s_load: lgkmcnt): a vector load's result could only be awaited with vmcnt, and a
+    // vmcnt wait at the top of an item would also wait for the previous item's stores, which nothing else has to.
+    auto fill_of = [&](uint32_t u) -> uint32_t {
+        if (u >= n_units) return 0u;
+        uint32_t v;
+        const uint32_t* p_ = L.log_fill + u;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p_) : "memory");
+        return v;
+    };
+    uint32_t unit = blockIdx.x, sub = 0, fill = fill_of(unit);
     auto settle = [&]() -> bool {      // move (unit, sub) to the next non-empty item at or after the current position
         for (;;) {
             if (unit >= n_units) return false;
             if (sub < kItemsPerChunk && fill > sub * kPartItem) return true;
-            unit += gridDim.x; sub = 0; fill = unit < n_units ? L.log_fill[unit] : 0u;
+            unit += gridDim.x; sub = 0; fill = fill_of(unit);
         }
     };
     // One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS[dst + lane * 16] (M0 = dst, wave-uniform).
@@ -435,19 +462,26 @@ __global__ void __launch_bounds__(kPartThreads, 8) k_log_part_lds(LogReduceParam
     auto lds_addr = [](const void* p_) -> uint32_t {
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(const __attribute__((address_space(3))) void*)p_);
     };
-    auto stage = [&](uint32_t lo, uint32_t buf) {      // LDS-DMA of the item that starts at record lo into staging buffer buf
+    auto stage_keys = [&](uint32_t lo) {               // LDS-DMA of the indices of the item that starts at record lo
         const uint32_t tid_ = threadIdx.x, w = tid_ >> 6, l = tid_ & 63u;
+        constexpr uint32_t nk = kPartItem * sizeof(uint32_t) / (THREADS * 16);      // instructions per wave
 #pragma unroll
-        for (uint32_t j = 0; j < 2; j++)
-            glds16(in_idx + lo + (w * 2 + j) * 256 + l * 4, lds_addr(sK + buf * kPartItem + (w * 2 + j) * 256));
-        constexpr uint32_t per = 16 / sizeof(TV), nj = kPartItem * sizeof(TV) / (8 * 1024);      // values per lane per instruction; instructions per wave
+        for (uint32_t j = 0; j < nk; j++)
+            glds16(in_idx + lo + (w * nk + j) * 256 + l * 4, lds_addr(sK + (w * nk + j) * 256));
+    };
+    auto stage_vals = [&](uint32_t lo, uint32_t buf) {      // ... and of its values, into staging buffer buf
+        const uint32_t tid_ = threadIdx.x, w = tid_ >> 6, l = tid_ & 63u;
+        constexpr uint32_t per = 16 / sizeof(TV), nj = kPartItem * sizeof(TV) / (THREADS * 16);      // values per lane per instruction; instructions per wave
 #pragma unroll
         for (uint32_t j = 0; j < nj; j++)
             glds16(in_val + lo + (w * nj + j) * (64 * per) + l * per, lds_addr(sV + buf * kPartItem + (w * nj + j) * (64 * per)));
     };
     if (!settle()) return;
     uint32_t buf = 0;
-    stage(unit * kLogChunk + sub * kPartItem, buf);
+    stage_keys(unit * kLogChunk + sub * kPartItem);
+    stage_vals(unit * kLogChunk + sub * kPartItem, buf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LT_PP_DECL;
     for (;;) {
         uint32_t tid = threadIdx.x;
         asm volatile("" : "+v"(tid));       // (lane-derived addresses and masks recomputed per item, not hoisted: see k_log_part)
@@ -456,18 +490,22 @@ __global__ void __launch_bounds__(kPartThreads, 8) k_log_part_lds(LogReduceParam
         sub++;
         const bool have_next = settle();
         uint32_t* cursor = L.cursor1 + (cur_unit & (kLogGroups - 1));
-        const uint32_t* kb = sK + buf * kPartItem;
+        const uint32_t next_lo = unit * kLogChunk + sub * kPartItem;       // (meaningful if have_next)
         const TV* vb = sV + buf * kPartItem;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this item's DMA (and the previous item's stores) are done ...
-        LT_LDS_BARRIER();                                     // ... in every wave; the other staging buffer is free
-        if (have_next) stage(unit * kLogChunk + sub * kPartItem, buf ^ 1u);
+        // This item's DMA has landed: the first item's was awaited in front of the loop, every other one was issued BEFORE the
+        // previous item's cursor atomics, whose results were awaited there (vmcnt counts in order).  No vmcnt wait here: the
+        // previous item's stores drain under this item's ranking.
+        LT_LDS_BARRIER();                                     // every wave is done with the sorted copy and the other staging buffer
+        LT_PP(0);
+        if (have_next) stage_vals(next_lo, buf ^ 1u);
         for (uint32_t d = tid; d < nb + 2; d += kPartThreads) s_a[d] = 0;
         LT_LDS_BARRIER();
+        LT_PP(1);
         // ---- rank inside the digit
         uint32_t key[kPerThread], ret2[kPerThread / 2];
 #pragma unroll
         for (int g = 0; g < kPerThread / 4; g++) {
-            const uint4 q = *reinterpret_cast<const uint4*>(kb + (uint32_t)g * (kPartThreads * 4) + tid * 4);
+            const uint4 q = *reinterpret_cast<const uint4*>(sK + (uint32_t)g * (kPartThreads * 4) + tid * 4);
             key[4 * g] = q.x; key[4 * g + 1] = q.y; key[4 * g + 2] = q.z; key[4 * g + 3] = q.w;
         }
 #pragma unroll
@@ -477,6 +515,8 @@ __global__ void __launch_bounds__(kPartThreads, 8) k_log_part_lds(LogReduceParam
             if (r & 1) ret2[r >> 1] |= rk << 16; else ret2[r >> 1] = rk;
         }
         LT_LDS_BARRIER();
+        LT_PP(2);
+        if (have_next) stage_keys(next_lo);      // every wave holds its indices in registers: the one index buffer takes the next item's
         // ---- space for every non-empty digit (one returning global atomic each), exclusive prefix over the digits
         uint32_t c0 = 0, c1 = 0, g0 = 0, g1 = 0, incl;
         {
@@ -500,6 +540,7 @@ __global__ void __launch_bounds__(kPartThreads, 8) k_log_part_lds(LogReduceParam
             if (d < nb) *reinterpret_cast<uint2*>(&s_a[d]) = make_uint2(ex, ex + c0);
         }
         LT_LDS_BARRIER();
+        LT_PP(3);
         // ---- digit-sorted copy in LDS (values straight from the staging buffer)
 #pragma unroll
         for (int g = 0; g < kPerThread / 4; g++) {
@@ -514,9 +555,10 @@ __global__ void __launch_bounds__(kPartThreads, 8) k_log_part_lds(LogReduceParam
                 }
             }
         }
+        LT_PP(4);
         // (the bases are "used" on every path: were their only use under if (c0) / if (c1), the path "atomic issued, use skipped"
         //  would exist for the compiler and it would wait for them -- vmcnt(0), the DMA with them -- before the next item's atomics)
-        asm volatile("" :: "v"(g0), "v"(g1));
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(g0), "v"(g1) : "memory");      // ... and with them the next item's DMA, issued before them
         LT_LDS_BARRIER();       // every lane has read its digits' offsets: the global bases take their place
         {
             const uint32_t d = 2 * tid;
@@ -524,6 +566,7 @@ __global__ void __launch_bounds__(kPartThreads, 8) k_log_part_lds(LogReduceParam
             if (c1) s_a[d + 1] = g1 - (ex + c0);
         }
         LT_LDS_BARRIER();
+        LT_PP(5);
         // ---- write out: consecutive sorted positions of one digit are consecutive in memory; the final pass keeps the
         //      14-bit position inside the tile only (2 bytes)
 #pragma unroll
@@ -536,10 +579,12 @@ __global__ void __launch_bounds__(kPartThreads, 8) k_log_part_lds(LogReduceParam
                 out_val[dst] = oV[p];
             }
         }
+        LT_PP(6);
         if (!have_next) break;
         buf ^= 1u;
         // (the barrier at the top of the next item separates these LDS reads from the next item's writes)
     }
+    LT_PP_FLUSH;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -817,28 +862,31 @@ template <int PASS, bool HOT> static hipError_t launch_part(const LogReduceParam
     if (L.tally == LT_TALLY_F64) return launch_part_t<double, PASS, HOT>(L, s);
     return launch_part_t<unsigned long long, PASS, HOT>(L, s);
 }
-template <typename TV> static hipError_t launch_part_lds_t(const LogReduceParams& L, hipStream_t s)
+template <typename TV, int THREADS> static hipError_t launch_part_lds_t(const LogReduceParams& L, hipStream_t s)
 {
-    const size_t lds = (size_t)kPartItem * (3 * sizeof(TV) + 3 * sizeof(uint32_t)) + (size_t)(kMaxBins + 2) * sizeof(uint32_t);
-    const void* fn = reinterpret_cast<const void*>(&k_log_part_lds<TV>);
+    const size_t lds = (size_t)kPartItem * (3 * sizeof(TV) + 2 * sizeof(uint32_t)) + (size_t)(kMaxBins + 2) * sizeof(uint32_t);
+    const void* fn = reinterpret_cast<const void*>(&k_log_part_lds<TV, THREADS>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     static BlockCache blocks{};
-    unsigned grid = persistent_blocks(blocks, fn, kPartThreads, lds) / kLogGroups * kLogGroups;      // a workgroup serves one cursor group
+    unsigned grid = persistent_blocks(blocks, fn, THREADS, lds) / kLogGroups * kLogGroups;      // a workgroup serves one cursor group
     if (grid < kLogGroups) grid = kLogGroups;
-    hipLaunchKernelGGL((k_log_part_lds<TV>), dim3(grid), dim3(kPartThreads), lds, s, L);
+    hipLaunchKernelGGL((k_log_part_lds<TV, THREADS>), dim3(grid), dim3(THREADS), lds, s, L);
     return hipGetLastError();
+}
+template <int THREADS> static hipError_t launch_part_lds(const LogReduceParams& L, hipStream_t s)
+{
+    if (L.tally == LT_TALLY_F32) return launch_part_lds_t<float, THREADS>(L, s);
+    if (L.tally == LT_TALLY_F64) return launch_part_lds_t<double, THREADS>(L, s);
+    return launch_part_lds_t<unsigned long long, THREADS>(L, s);
 }
 
 hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s)
 {
-    if (L.lds_part) {      // lt_set_tuning "part_lds": 1 = where it applies (one-pass grids), 2 = or fail (tests: proves the route)
-        if (!L.dmap && L.bits2 == 0 && L.n_tiles <= (uint32_t)kMaxBins) {
-            if (L.tally == LT_TALLY_F32) return launch_part_lds_t<float>(L, s);
-            if (L.tally == LT_TALLY_F64) return launch_part_lds_t<double>(L, s);
-            return launch_part_lds_t<unsigned long long>(L, s);
-        }
-        if (L.lds_part == 2) return hipErrorInvalidValue;
+    if (L.lds_part) {      // lt_set_tuning "part_lds": bit 0 = where it applies (one-pass grids), bit 1 = or fail (tests: proves the route), bit 2 = 1024 lanes
+        if (!L.dmap && L.bits2 == 0 && L.n_tiles <= (uint32_t)kMaxBins)
+            return (L.lds_part & 4) ? launch_part_lds<1024>(L, s) : launch_part_lds<512>(L, s);
+        if (L.lds_part & 2) return hipErrorInvalidValue;
     }
     if (L.dmap) {
         if (L.bits2 == 0 || L.n_tiles > kMaxHotTiles) return hipErrorInvalidValue;
@@ -891,3 +939,14 @@ hipError_t launch_log_reduce(const LogReduceParams& L, hipStream_t s)
 }
 
 }  // namespace ltk
+
+#ifdef LT_PART_PROF
+extern "C" int lt_diag_part_phases(unsigned long long* out8, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(ltk::g_part_phase), 8 * sizeof(unsigned long long)) != hipSuccess) return 2;
+    static const unsigned long long zero[8] = {};
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(ltk::g_part_phase), zero, sizeof(zero)) != hipSuccess) return 3;
+    return 0;
+}
+#endif

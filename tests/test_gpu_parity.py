@@ -1069,8 +1069,9 @@ def test_lds_staged_partition_equals_the_register_staged_one(ctx):
     """lt_set_tuning "part_lds" (k_log_part_lds: the next item arrives by LDS-DMA while this one is sorted) against the default
     partition and the atomic tally: bit-identical fixed-point grids -- ample log, a log budget that forces several batches
     (short last chunks, chunks nobody claimed), two lanes, a grid that is not a multiple of the tile, a mesh scene, and a
-    launch so small that most items are ragged.  part_lds = 2 makes lt_launch FAIL where that partition cannot run, so a launch
-    that succeeds has taken it; the two-pass grid checks that the failure is real (the knob reaches the launcher)."""
+    launch so small that most items are ragged; its 512-lane and 1024-lane builds.  Bit 1 of part_lds (values 2, 6) makes
+    lt_launch FAIL where that partition cannot run, so a launch that succeeds has taken it; the two-pass grid checks that the
+    failure is real (the knob reaches the launcher)."""
     import light_transport_amd as lt
     odd = S.Problem([(0.1, 10.0, 0.9, 1.0)], (100, 70, 33), (-5.0, -3.5, 0.0), (0.1,) * 3,
                     layers=dict(z_bounds=[0.0, np.inf], medium_idx=[0]))
@@ -1081,7 +1082,7 @@ def test_lds_staged_partition_equals_the_register_staged_one(ctx):
         ctx.launch(n, seed=11); ctx.sync()
         ref, cref = ctx.read_grid_raw(), ctx.read_counters()
         for log_bytes, lanes in ((8 << 30, 1), (48 << 20, 1), (8 << 30, 2), (48 << 20, 2)):
-            for part_lds in (0, 2):
+            for part_lds in (0, 2, 6):
                 with ctx.tuning(part_lds=part_lds):
                     prob.apply(ctx, "u64fx"); ctx.set_tally_mode("log", log_bytes); ctx.set_overlap(lanes)
                     ctx.launch(n, seed=11); ctx.sync()

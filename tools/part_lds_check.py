@@ -15,8 +15,8 @@ for dtype in ("u64fx", "f64"):      # fixed point: bit-identical whatever the or
   prob.apply(ctx, dtype); ctx.set_tally_mode("log"); ctx.set_overlap(1)
   ref = None
   print("tally", dtype)
-  for label, knobs in (("registers", {}), ("lds-dma", {"part_lds": 1}), ("registers, alone grid", {"part_alone": 1}),
-                     ("lds-dma, alone grid", {"part_lds": 1, "part_alone": 1})):
+  for label, knobs in (("registers", {}), ("lds-dma, 512 lanes", {"part_lds": 2}), ("registers, alone grid", {"part_alone": 1}),
+                       ("lds-dma, 1024 lanes", {"part_lds": 6})):
       with ctx.tuning(**knobs):
           best = None
           for r in range(3):
