@@ -161,11 +161,12 @@ int lt_set_max_steps(lt_ctx* ctx, uint32_t max_steps);
  *                      photons to the tail kernel when at most 32 lanes are alive) where a drain is exposed and the batch
  *                      has >= 512 photons per launched wave; n >= 2 = split with threshold n (<= 48) whatever the size
  *   part_alone         0 / 1: pin the partition build that shares the CU with a walk / the one for an otherwise idle device
- *   part_lds           one-pass grids (<= 1024 tiles): the partition that stages its NEXT 4096 records by LDS-DMA while it sorts
- *                      this one -- one workgroup per CU with 136 KiB of LDS and <= 58 VGPRs, for a partition that has to live
- *                      in the register quarter a walk train leaves free (on an idle device it equals the default build within
- *                      5 %).  Bits: 1 = use it where it applies; 2 = and make lt_launch fail where it does not (two-pass
- *                      grids; tests); 4 = 1024 lanes per workgroup instead of 512
+ *   part_lds           one-pass grids (<= 1024 tiles): the partition that stages its NEXT item by LDS-DMA while it sorts this one
+ *                      -- one workgroup per CU, 136 KiB of LDS, <= 62 VGPRs, no second workgroup needed to hide its loads
+ *                      (on an idle device it equals the default build within 5 %).  Bits: 1 = use it where it applies; 2 = and
+ *                      make lt_launch fail where it does not (two-pass grids; tests); 4 = the ONE-WAVE-PER-SIMD builds of the
+ *                      partition (256 lanes, items of 2048 records, 68 KiB) and of the tile reduce (256 lanes) -- what fits
+ *                      beside four walk waves of <= 112 VGPRs (measurement; DESIGN "Overlap")
  *   serial_walks       1: WALK TRAIN -- the walk kernels of every context of this device that sets the knob run one after
  *                      another (each waits for the end of the one enqueued before it; the log reductions stay on their own
  *                      streams).  For hosts that keep several jobs in flight: launch each walk at three of the four resident

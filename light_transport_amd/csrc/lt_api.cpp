@@ -883,14 +883,6 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         HIP_TRY(c, lane_event(ln, s));
         HIP_TRY(c, launch_walk(P, vw, cfg, s));
         HIP_TRY(c, lane_event(ln, s));
-        if (train) {
-            WalkGate& g = walk_gate(c->device);
-            std::lock_guard<std::mutex> lk(g.mu);
-            hipEvent_t& ev = g.ring[g.next++ & 63u];
-            if (!ev) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            HIP_TRY(c, hipEventRecord(ev, s));
-            g.last = ev;
-        }
         if (split) {
             HIP_TRY(c, hipEventRecord(ln.ev_bulk, s));
             HIP_TRY(c, hipStreamWaitEvent(ln.tail_stream, ln.ev_bulk, 0));
@@ -906,6 +898,15 @@ int run_log_plan(LogRun& R, const LogPlan& plan, uint64_t offset, int* n_batches
         }
         if (hot) HIP_TRY(c, launch_log_count1(L, s));
         HIP_TRY(c, G.bits2 ? launch_log_scan_bins(L, s) : launch_log_scan_tiles(L, s));
+        if (train) {      // the next walk of the train may start: behind this batch's walk AND its scan -- a 1024-lane workgroup that finds
+                          // no CU to run on once the next walk has filled them all (seen: a scan that waited 30 ms for a walk to end)
+            WalkGate& g = walk_gate(c->device);
+            std::lock_guard<std::mutex> lk(g.mu);
+            hipEvent_t& ev = g.ring[g.next++ & 63u];
+            if (!ev) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIP_TRY(c, hipEventRecord(ev, s));
+            g.last = ev;
+        }
         HIP_TRY(c, lane_event(ln, s));
         HIP_TRY(c, launch_log_part1(L, s));
         LogReduceParams Lr = L;

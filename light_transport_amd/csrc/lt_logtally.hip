@@ -221,6 +221,9 @@ __device__ __forceinline__ uint32_t claimed_chunks(const LogReduceParams& L)
 template <typename TV, int PASS, bool HOT, bool ALONE>
 __global__ void __launch_bounds__(kPartThreads, ALONE ? LT_PART_WAVES_ALONE : LT_PART_WAVES_CORUN) k_log_part(LogReduceParams L)
 {
+#if LT_RED_PRIO      // (compile option: the log reduction's waves issue ahead of a walk's -- they need 8 % of its VALU work and sit on the critical path of their job)
+    __builtin_amdgcn_s_setprio(LT_RED_PRIO);
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     TV* s_val = reinterpret_cast<TV*>(s_dyn);                                                   // [kPartItem]
     uint32_t* s_key = reinterpret_cast<uint32_t*>(s_dyn + (size_t)kPartItem * sizeof(TV));      // [kPartItem]
@@ -398,9 +401,11 @@ __global__ void __launch_bounds__(kPartThreads, ALONE ? LT_PART_WAVES_ALONE : LT
 // which leaves three slab walk workgroups their 4.6 KiB each.  One vmcnt wait per item: where the cursor atomics' results are
 // needed -- the DMA was issued before them and vmcnt counts in order, so it has landed too; the item's own stores drain under
 // the next item's ranking.  Barriers are raw s_barrier with an lgkmcnt-only wait.  Measured (C2, 1.81e9 records): 10.5 ms
-// against k_log_part's 10.1 on an idle device (both ~3.8 TB/s: the bound is the scattered write-out, not latency -- 1024
-// lanes per workgroup change nothing, and the per-phase clocks of tools/part_phases.py are flat); beside a walk train it runs
-// at the walk's length (37-39 ms), and no jobs-in-flight regime gains from it -- hence a knob, not the default.
+// against k_log_part's 10.1-10.4 on an idle device (both ~3.8 TB/s: the bound is the scattered write-out, not latency -- 1024
+// lanes per workgroup changed nothing, and the per-phase clocks of tools/part_phases.py are flat).  THREADS = 256: one wave per
+// SIMD, items of 2048 records (8 per lane as at 512), 68 KiB -- the build that fits beside FOUR walk waves of <= 112 VGPRs
+// (14.3 ms alone).  No jobs-in-flight regime gains from either (DESIGN "Overlap": a walk loses about what the reduction beside
+// it takes, whatever registers it leaves) -- hence a knob, not the default.
 #ifdef LT_PART_PROF      // measurement builds only (tools/build_variant.sh): clock sums per phase of k_log_part_lds, first wave of every workgroup
 __device__ unsigned long long g_part_phase[8];
 #define LT_PP_DECL unsigned long long pp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pp_t = __builtin_readcyclecounter()
@@ -412,18 +417,24 @@ __device__ unsigned long long g_part_phase[8];
 #define LT_PP_FLUSH
 #endif
 #define LT_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+constexpr uint32_t lds_part_item(int threads) { return threads >= 512 ? kPartItem : (uint32_t)threads * 8u; }
 template <typename TV, int THREADS>
 __global__ void __launch_bounds__(THREADS, 8) k_log_part_lds(LogReduceParams L)
 {
-    constexpr int kPerThread = (int)kPartItem / THREADS;      // (shadows the register-staged kernel's: 8 at 512 lanes, 4 at 1024)
+#if LT_RED_PRIO      // (compile option: the log reduction's waves issue ahead of a walk's -- they need 8 % of its VALU work and sit on the critical path of their job)
+    __builtin_amdgcn_s_setprio(LT_RED_PRIO);
+#endif
+    constexpr uint32_t kItem = lds_part_item(THREADS), kItems = kLogChunk / kItem;      // records per item (8 per lane); items per log chunk
+    constexpr int kPerThread = (int)kItem / THREADS;      // (shadows the register-staged kernel's: 8 at 512 lanes, 4 at 1024)
     constexpr uint32_t kPartThreads = THREADS;
-    static_assert(kPerThread % 4 == 0 && 2 * THREADS >= kMaxBins, "a lane reads its records four at a time and owns two digits");
+    constexpr int DPL = kMaxBins / THREADS > 2 ? kMaxBins / THREADS : 2;      // digits a lane owns in the scan
+    static_assert(kPerThread % 4 == 0 && DPL * THREADS >= kMaxBins, "a lane reads its records four at a time; the lanes own all digits");
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    uint32_t* sK = reinterpret_cast<uint32_t*>(s_dyn);                                                           // [kPartItem] staged indices (ONE buffer: in registers after the ranking's first read)
-    TV* sV = reinterpret_cast<TV*>(s_dyn + (size_t)kPartItem * sizeof(uint32_t));                                 // [2][kPartItem] staged values
-    TV* oV = sV + 2 * (size_t)kPartItem;                                                                          // [kPartItem] digit-sorted values
-    uint32_t* oK = reinterpret_cast<uint32_t*>(oV + kPartItem);                                                   // [kPartItem] digit-sorted indices
-    uint32_t* s_a = oK + kPartItem;                                                                               // [kMaxBins + 2] counts -> offsets -> global bases
+    uint32_t* sK = reinterpret_cast<uint32_t*>(s_dyn);                                                           // [kItem] staged indices (ONE buffer: in registers after the ranking's first read)
+    TV* sV = reinterpret_cast<TV*>(s_dyn + (size_t)kItem * sizeof(uint32_t));                                 // [2][kItem] staged values
+    TV* oV = sV + 2 * (size_t)kItem;                                                                          // [kItem] digit-sorted values
+    uint32_t* oK = reinterpret_cast<uint32_t*>(oV + kItem);                                                   // [kItem] digit-sorted indices
+    uint32_t* s_a = oK + kItem;                                                                               // [kMaxBins + 2] counts -> offsets -> global bases
     __shared__ uint32_t s_wsum[kPartThreads / 64];
     const uint32_t nb = L.n_tiles;
     const uint32_t n_units = claimed_chunks(L);
@@ -446,7 +457,7 @@ __global__ void __launch_bounds__(THREADS, 8) k_log_part_lds(LogReduceParams L)
     auto settle = [&]() -> bool {      // move (unit, sub) to the next non-empty item at or after the current position
         for (;;) {
             if (unit >= n_units) return false;
-            if (sub < kItemsPerChunk && fill > sub * kPartItem) return true;
+            if (sub < kItems && fill > sub * kItem) return true;
             unit += gridDim.x; sub = 0; fill = fill_of(unit);
         }
     };
@@ -464,40 +475,45 @@ __global__ void __launch_bounds__(THREADS, 8) k_log_part_lds(LogReduceParams L)
     };
     auto stage_keys = [&](uint32_t lo) {               // LDS-DMA of the indices of the item that starts at record lo
         const uint32_t tid_ = threadIdx.x, w = tid_ >> 6, l = tid_ & 63u;
-        constexpr uint32_t nk = kPartItem * sizeof(uint32_t) / (THREADS * 16);      // instructions per wave
+        constexpr uint32_t nk = kItem * sizeof(uint32_t) / (THREADS * 16);      // instructions per wave
 #pragma unroll
         for (uint32_t j = 0; j < nk; j++)
             glds16(in_idx + lo + (w * nk + j) * 256 + l * 4, lds_addr(sK + (w * nk + j) * 256));
     };
     auto stage_vals = [&](uint32_t lo, uint32_t buf) {      // ... and of its values, into staging buffer buf
         const uint32_t tid_ = threadIdx.x, w = tid_ >> 6, l = tid_ & 63u;
-        constexpr uint32_t per = 16 / sizeof(TV), nj = kPartItem * sizeof(TV) / (THREADS * 16);      // values per lane per instruction; instructions per wave
+        constexpr uint32_t per = 16 / sizeof(TV), nj = kItem * sizeof(TV) / (THREADS * 16);      // values per lane per instruction; instructions per wave
 #pragma unroll
         for (uint32_t j = 0; j < nj; j++)
-            glds16(in_val + lo + (w * nj + j) * (64 * per) + l * per, lds_addr(sV + buf * kPartItem + (w * nj + j) * (64 * per)));
+            glds16(in_val + lo + (w * nj + j) * (64 * per) + l * per, lds_addr(sV + buf * kItem + (w * nj + j) * (64 * per)));
     };
     if (!settle()) return;
+#if LT_PART_DROP == 9      // (measurement builds: no partition at all)
+    return;
+#endif
     uint32_t buf = 0;
-    stage_keys(unit * kLogChunk + sub * kPartItem);
-    stage_vals(unit * kLogChunk + sub * kPartItem, buf);
+    stage_keys(unit * kLogChunk + sub * kItem);
+    stage_vals(unit * kLogChunk + sub * kItem, buf);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LT_PP_DECL;
     for (;;) {
         uint32_t tid = threadIdx.x;
         asm volatile("" : "+v"(tid));       // (lane-derived addresses and masks recomputed per item, not hoisted: see k_log_part)
         const int lane = (int)(tid & 63u), wave = (int)(tid >> 6);
-        const uint32_t cur_unit = unit, n = fill - sub * kPartItem < kPartItem ? fill - sub * kPartItem : kPartItem;
+        const uint32_t cur_unit = unit, n = fill - sub * kItem < kItem ? fill - sub * kItem : kItem;
         sub++;
         const bool have_next = settle();
         uint32_t* cursor = L.cursor1 + (cur_unit & (kLogGroups - 1));
-        const uint32_t next_lo = unit * kLogChunk + sub * kPartItem;       // (meaningful if have_next)
-        const TV* vb = sV + buf * kPartItem;
+        const uint32_t next_lo = unit * kLogChunk + sub * kItem;       // (meaningful if have_next)
+        const TV* vb = sV + buf * kItem;
         // This item's DMA has landed: the first item's was awaited in front of the loop, every other one was issued BEFORE the
         // previous item's cursor atomics, whose results were awaited there (vmcnt counts in order).  No vmcnt wait here: the
         // previous item's stores drain under this item's ranking.
         LT_LDS_BARRIER();                                     // every wave is done with the sorted copy and the other staging buffer
         LT_PP(0);
+#if LT_PART_DROP != 3
         if (have_next) stage_vals(next_lo, buf ^ 1u);
+#endif
         for (uint32_t d = tid; d < nb + 2; d += kPartThreads) s_a[d] = 0;
         LT_LDS_BARRIER();
         LT_PP(1);
@@ -511,20 +527,27 @@ __global__ void __launch_bounds__(THREADS, 8) k_log_part_lds(LogReduceParams L)
 #pragma unroll
         for (int r = 0; r < kPerThread; r++) {
             const uint32_t k = (uint32_t)(r >> 2) * (kPartThreads * 4) + tid * 4 + (r & 3);
+#if LT_PART_DROP == 1      // (measurement builds: which of the partition's resources slows a walk beside it -- results are garbage)
+            const uint32_t rk = 0u;
+#else
             const uint32_t rk = k < n ? atomicAdd(&s_a[tile_of(key[r])], 1u) : 0u;
+#endif
             if (r & 1) ret2[r >> 1] |= rk << 16; else ret2[r >> 1] = rk;
         }
         LT_LDS_BARRIER();
         LT_PP(2);
+#if LT_PART_DROP != 3
         if (have_next) stage_keys(next_lo);      // every wave holds its indices in registers: the one index buffer takes the next item's
+#endif
         // ---- space for every non-empty digit (one returning global atomic each), exclusive prefix over the digits
-        uint32_t c0 = 0, c1 = 0, g0 = 0, g1 = 0, incl;
+        uint32_t c[DPL], g[DPL], incl, sum = 0;
         {
-            const uint32_t d = 2 * tid;
-            if (d < nb) { const uint2 cc = *reinterpret_cast<const uint2*>(&s_a[d]); c0 = cc.x; c1 = d + 1 < nb ? cc.y : 0; }
-            if (c0) g0 = atomicAdd(&cursor[d * kLogGroups], c0);
-            if (c1) g1 = atomicAdd(&cursor[(d + 1) * kLogGroups], c1);
-            incl = c0 + c1;
+            const uint32_t d0 = DPL * tid;
+#pragma unroll
+            for (int i = 0; i < DPL; i++) { c[i] = d0 + i < nb ? s_a[d0 + i] : 0u; g[i] = 0; }
+#pragma unroll
+            for (int i = 0; i < DPL; i++) { if (c[i]) g[i] = atomicAdd(&cursor[(d0 + i) * kLogGroups], c[i]); sum += c[i]; }
+            incl = sum;
 #pragma unroll
             for (int off2 = 1; off2 < 64; off2 <<= 1) { const uint32_t o = __shfl_up(incl, off2, 64); if (lane >= off2) incl += o; }
             if (lane == 63) s_wsum[wave] = incl;
@@ -534,10 +557,12 @@ __global__ void __launch_bounds__(THREADS, 8) k_log_part_lds(LogReduceParams L)
         {
             uint32_t before = 0;
 #pragma unroll
-            for (int w = 0; w < kPartThreads / 64; w++) before += w < wave ? s_wsum[w] : 0;
-            ex = before + incl - (c0 + c1);
-            const uint32_t d = 2 * tid;
-            if (d < nb) *reinterpret_cast<uint2*>(&s_a[d]) = make_uint2(ex, ex + c0);
+            for (int w = 0; w < (int)(kPartThreads / 64); w++) before += w < wave ? s_wsum[w] : 0;
+            ex = before + incl - sum;
+            const uint32_t d0 = DPL * tid;
+            uint32_t run = ex;
+#pragma unroll
+            for (int i = 0; i < DPL; i++) { if (d0 + i < nb) s_a[d0 + i] = run; run += c[i]; }
         }
         LT_LDS_BARRIER();
         LT_PP(3);
@@ -551,19 +576,26 @@ __global__ void __launch_bounds__(THREADS, 8) k_log_part_lds(LogReduceParams L)
                 const uint32_t k = (uint32_t)g * (kPartThreads * 4) + tid * 4 + (uint32_t)j;
                 if (k < n) {
                     const uint32_t p = s_a[tile_of(key[r])] + ((r & 1) ? ret2[r >> 1] >> 16 : (ret2[r >> 1] & 0xffffu));
+#if LT_PART_DROP == 4
+                    asm volatile("" :: "v"(p), "v"(v.v[j]));
+#else
                     oK[p] = key[r]; oV[p] = v.v[j];
+#endif
                 }
             }
         }
         LT_PP(4);
         // (the bases are "used" on every path: were their only use under if (c0) / if (c1), the path "atomic issued, use skipped"
         //  would exist for the compiler and it would wait for them -- vmcnt(0), the DMA with them -- before the next item's atomics)
-        asm volatile("s_waitcnt vmcnt(0)" :: "v"(g0), "v"(g1) : "memory");      // ... and with them the next item's DMA, issued before them
+#pragma unroll
+        for (int i = 0; i < DPL; i++) asm volatile("" :: "v"(g[i]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ... and with them the next item's DMA, issued before them
         LT_LDS_BARRIER();       // every lane has read its digits' offsets: the global bases take their place
         {
-            const uint32_t d = 2 * tid;
-            if (c0) s_a[d] = g0 - ex;
-            if (c1) s_a[d + 1] = g1 - (ex + c0);
+            const uint32_t d0 = DPL * tid;
+            uint32_t run = ex;
+#pragma unroll
+            for (int i = 0; i < DPL; i++) { if (c[i]) s_a[d0 + i] = g[i] - run; run += c[i]; }
         }
         LT_LDS_BARRIER();
         LT_PP(5);
@@ -575,8 +607,12 @@ __global__ void __launch_bounds__(THREADS, 8) k_log_part_lds(LogReduceParams L)
             if (p < n) {
                 const uint32_t kk = oK[p];
                 const uint32_t dst = s_a[tile_of(kk)] + p;
+#if LT_PART_DROP == 2
+                asm volatile("" :: "v"(dst), "v"(oV[p]));
+#else
                 reinterpret_cast<uint16_t*>(out_idx)[dst] = (uint16_t)(kk & (kTileSize - 1));
                 out_val[dst] = oV[p];
+#endif
             }
         }
         LT_PP(6);
@@ -713,9 +749,13 @@ __device__ __forceinline__ void add8(AT* s_tile, const uint4 q, const Quad<TV>& 
     lds_add(&s_tile[q.w & m], (AT)b.v[2]); lds_add(&s_tile[(q.w >> 16) & m], (AT)b.v[3]);
 }
 
-template <typename TV>
-__global__ void __launch_bounds__(kReduceThreads, LT_REDUCE_WAVES) k_log_reduce(LogReduceParams L)
+template <typename TV, int THREADS>
+__global__ void __launch_bounds__(THREADS, LT_REDUCE_WAVES) k_log_reduce(LogReduceParams L)
 {
+    constexpr uint32_t kReduceThreads = THREADS;      // (512; 256 = one wave per SIMD, for the register quarter beside four 112-VGPR walk waves)
+#if LT_RED_PRIO      // (compile option: the log reduction's waves issue ahead of a walk's -- they need 8 % of its VALU work and sit on the critical path of their job)
+    __builtin_amdgcn_s_setprio(LT_RED_PRIO);
+#endif
     typedef typename AccT<TV>::type AT;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     AT* s_tile = reinterpret_cast<AT*>(s_raw);
@@ -819,7 +859,7 @@ hipError_t launch_log_plan(const uint32_t* tile_cnt, uint32_t n_tiles, uint32_t 
 // kernel (a benign race: every thread computes the same number)
 constexpr int kMaxDevices = 16;      // occupancy of a kernel is cached per device: a process may drive GPUs that differ (lt_create takes a device id)
 struct BlockCache { std::atomic<unsigned> per_dev[kMaxDevices]; };
-static unsigned persistent_blocks(BlockCache& cache, const void* fn, int threads, size_t lds)
+static unsigned persistent_blocks(BlockCache& cache, const void* fn, int threads, size_t lds, int max_per_cu = 0)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
@@ -828,6 +868,7 @@ static unsigned persistent_blocks(BlockCache& cache, const void* fn, int threads
     if (b) return b;
     int per_cu = 0, cus = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     b = (unsigned)(per_cu * cus);
@@ -864,12 +905,12 @@ template <int PASS, bool HOT> static hipError_t launch_part(const LogReduceParam
 }
 template <typename TV, int THREADS> static hipError_t launch_part_lds_t(const LogReduceParams& L, hipStream_t s)
 {
-    const size_t lds = (size_t)kPartItem * (3 * sizeof(TV) + 2 * sizeof(uint32_t)) + (size_t)(kMaxBins + 2) * sizeof(uint32_t);
+    const size_t lds = (size_t)lds_part_item(THREADS) * (3 * sizeof(TV) + 2 * sizeof(uint32_t)) + (size_t)(kMaxBins + 2) * sizeof(uint32_t);
     const void* fn = reinterpret_cast<const void*>(&k_log_part_lds<TV, THREADS>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     static BlockCache blocks{};
-    unsigned grid = persistent_blocks(blocks, fn, THREADS, lds) / kLogGroups * kLogGroups;      // a workgroup serves one cursor group
+    unsigned grid = persistent_blocks(blocks, fn, THREADS, lds, 1) / kLogGroups * kLogGroups;      // one per CU; a workgroup serves one cursor group
     if (grid < kLogGroups) grid = kLogGroups;
     hipLaunchKernelGGL((k_log_part_lds<TV, THREADS>), dim3(grid), dim3(THREADS), lds, s, L);
     return hipGetLastError();
@@ -885,7 +926,7 @@ hipError_t launch_log_part1(const LogReduceParams& L, hipStream_t s)
 {
     if (L.lds_part) {      // lt_set_tuning "part_lds": bit 0 = where it applies (one-pass grids), bit 1 = or fail (tests: proves the route), bit 2 = 1024 lanes
         if (!L.dmap && L.bits2 == 0 && L.n_tiles <= (uint32_t)kMaxBins)
-            return (L.lds_part & 4) ? launch_part_lds<1024>(L, s) : launch_part_lds<512>(L, s);
+            return (L.lds_part & 4) ? launch_part_lds<256>(L, s) : launch_part_lds<512>(L, s);
         if (L.lds_part & 2) return hipErrorInvalidValue;
     }
     if (L.dmap) {
@@ -919,23 +960,27 @@ hipError_t launch_log_part2(const LogReduceParams& L, hipStream_t s)
     return launch_part<2, false>(L, s);
 }
 
-template <typename TV> static hipError_t launch_reduce_t(const LogReduceParams& L, hipStream_t s)
+template <typename TV, int THREADS> static hipError_t launch_reduce_t(const LogReduceParams& L, hipStream_t s)
 {
     const size_t lds = (size_t)kTileSize * sizeof(typename AccT<TV>::type);
-    const void* fn = reinterpret_cast<const void*>(&k_log_reduce<TV>);
+    const void* fn = reinterpret_cast<const void*>(&k_log_reduce<TV, THREADS>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     static BlockCache blocks{};
-    hipLaunchKernelGGL(k_log_reduce<TV>, dim3(persistent_blocks(blocks, fn, kReduceThreads, lds)), dim3(kReduceThreads), lds, s, L);
+    hipLaunchKernelGGL((k_log_reduce<TV, THREADS>), dim3(persistent_blocks(blocks, fn, THREADS, lds, 1)), dim3(THREADS), lds, s, L);
     return hipGetLastError();
+}
+template <int THREADS> static hipError_t launch_reduce_n(const LogReduceParams& L, hipStream_t s)
+{
+    if (L.tally == LT_TALLY_F32) return launch_reduce_t<float, THREADS>(L, s);
+    if (L.tally == LT_TALLY_F64) return launch_reduce_t<double, THREADS>(L, s);
+    return launch_reduce_t<unsigned long long, THREADS>(L, s);
 }
 hipError_t launch_log_reduce(const LogReduceParams& L, hipStream_t s)
 {
-    if (L.tally == LT_TALLY_F32) return launch_reduce_t<float>(L, s);
-    if (L.tally == LT_TALLY_F64) return launch_reduce_t<double>(L, s);
-    return launch_reduce_t<unsigned long long>(L, s);
+    return (L.lds_part & 4) ? launch_reduce_n<256>(L, s) : launch_reduce_n<kReduceThreads>(L, s);
 }
 
 }  // namespace ltk

@@ -1069,7 +1069,8 @@ def test_lds_staged_partition_equals_the_register_staged_one(ctx):
     """lt_set_tuning "part_lds" (k_log_part_lds: the next item arrives by LDS-DMA while this one is sorted) against the default
     partition and the atomic tally: bit-identical fixed-point grids -- ample log, a log budget that forces several batches
     (short last chunks, chunks nobody claimed), two lanes, a grid that is not a multiple of the tile, a mesh scene, and a
-    launch so small that most items are ragged; its 512-lane and 1024-lane builds.  Bit 1 of part_lds (values 2, 6) makes
+    launch so small that most items are ragged; its 512-lane build and the one-wave-per-SIMD builds (256-lane partition with
+    2048-record items + 256-lane tile reduce: bit 2).  Bit 1 of part_lds (values 2, 6) makes
     lt_launch FAIL where that partition cannot run, so a launch that succeeds has taken it; the two-pass grid checks that the
     failure is real (the knob reaches the launcher)."""
     import light_transport_amd as lt

@@ -16,7 +16,7 @@ for dtype in ("u64fx", "f64"):      # fixed point: bit-identical whatever the or
   ref = None
   print("tally", dtype)
   for label, knobs in (("registers", {}), ("lds-dma, 512 lanes", {"part_lds": 2}), ("registers, alone grid", {"part_alone": 1}),
-                       ("lds-dma, 1024 lanes", {"part_lds": 6})):
+                       ("lds-dma, 256 lanes (+ 256-lane reduce)", {"part_lds": 6})):
       with ctx.tuning(**knobs):
           best = None
           for r in range(3):
@@ -26,7 +26,7 @@ for dtype in ("u64fx", "f64"):      # fixed point: bit-identical whatever the or
           t = np.asarray(ctx.read_grid_raw()).copy()
       if ref is None: ref = t
       same = bool((t == ref).all()) if dtype == "u64fx" else bool(np.allclose(t, ref, rtol=1e-12, atol=0))
-      print("%-24s partition %6.2f ms  reduce %5.2f  walk %6.2f | tally identical to the first: %s  (sum %r)" % (
+      print("%-40s partition %6.2f ms  reduce %5.2f  walk %6.2f | tally identical to the first: %s  (sum %r)" % (
           label, best["partition_ms"], best["reduce_ms"], best["walk_ms"], same, float(t.sum())), flush=True)
       assert same, "the staged partition changed the tally"
 ctx.close()

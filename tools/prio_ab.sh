@@ -8,7 +8,7 @@ LABEL="prio three_jobs part_lds" ENVS="LT_HIP_LIBRARY=$V LT_PART_LDS=1" run 3
 LABEL="ship walk_train" ENVS="A=1" run 4
 LABEL="prio walk_train" ENVS="LT_HIP_LIBRARY=$V" run 4
 LABEL="prio walk_train part_lds" ENVS="LT_HIP_LIBRARY=$V LT_PART_LDS=1" run 4
-LABEL="prio two_jobs" ENVS="LT_HIP_LIBRARY=$V" run 2
-LABEL="prio one_call" ENVS="LT_HIP_LIBRARY=$V" run 1
+
+
 LABEL="ship one_call" ENVS="A=1" run 1
 LABEL="ship three_jobs" ENVS="A=1" run 3

@@ -9,7 +9,10 @@ rows = rows[-n:]
 t0 = int(rows[0]["Start_Timestamp"])
 for r in rows:
     name = r["Kernel_Name"]
-    short = "walk" + (name[name.index("WalkParams") - 6:name.index("WalkParams") - 3] if "walk_kernel" in name else "") if "walk_kernel" in name else (
-        name[name.index("k_log_"):].split("(")[0].split("<")[0] if "k_log_" in name else name[:24])
+    if "walk_kernel" in name:
+        args = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",")      # R, GEOM, TABLE, TALLY, CAPTURE[, PHASE]
+        short = "walk" + {"0": "", "1": " main", "2": " TAIL"}.get(args[5] if len(args) > 5 else "0", "?")
+    else:
+        short = name[name.index("k_log_"):].split("(")[0].split("<")[0] if "k_log_" in name else name[:24]
     print("%-16s q%-3s %9.3f -> %9.3f  (%7.3f ms)" % (short, r.get("Queue_Id", "?"), (int(r["Start_Timestamp"]) - t0) / 1e6,
                                                      (int(r["End_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
