@@ -102,8 +102,7 @@ struct SurvD {
     int32_t cur;
     uint32_t step;
     uint32_t rng[6];
-    uint32_t held[2];        // mesh walks: the deflection uniforms of a prepared step that waits for its surface query (HeldU bits)
-    uint32_t pad_;
+    uint32_t held[3];        // mesh walks: the decision uniforms of a prepared step that waits for its surface query (HeldU bits)
     uint32_t q_pend;         //             ... and whether there is one
 };
 constexpr uint32_t kDumpMaxLanes = 32;     // a wave hands its photons over when the queue is empty and at most this many are alive (default)

@@ -594,7 +594,7 @@ template <typename R> struct MarchWave {        // per wave, in LDS
     typename MarchBits<R>::type slot_t[64];     // best t per ray (bits), starts at the ray's tmax
     unsigned slot_i[64];                        // triangle of that t (lowest id on ties)
     R ray[9][64];                               // origin, direction, 1 / direction (inf for an axis the ray does not move along)
-    R held[3][64];                              // walk_kernel_m: the prepared step of a lane in a query (free path, two deflection uniforms)
+    R held[4][64];                              // walk_kernel_m: the prepared step of a lane in a query (free path, three decision uniforms)
     unsigned q_item[kMarchQ];                   // lane << 26 | position in MarchGrid::list
     typename MarchBits<R>::type q_t[kMarchQ];   // t of the item's test (all ones: no hit)
 };
