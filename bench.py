@@ -423,9 +423,9 @@ def main(argv=None):
     if wl["grid"] <= 256:
         REGIMES["three_jobs"] = (3, 1)
     # walk_train: jobs in flight whose WALKS run one after another (lt_set_tuning "serial_walks"), each at 3 of the 4 resident
-    # workgroups per CU (f32: 4 of 5) -- 92 % of a full walk's speed -- while the free quarter of every SIMD's register file
-    # carries the previous job's partition and tile reduce.  Two walks side by side at half occupancy each (two_jobs,
-    # three_jobs) fill the same registers but leave the reductions nothing until one of them ends.
+    # workgroups per CU (f32: 4 of 5) while the free quarter of every SIMD's register file carries the previous job's partition
+    # and tile reduce.  Measured behind three_jobs on every workload by the end of round 4 (DESIGN.md "Overlap": a walk loses
+    # speed in proportion to the residency it gives up); kept in the probe as a measured alternative.
     if not args.f32_walk:
         REGIMES["walk_train"] = (int(os.environ.get("LT_BENCH_TRAIN_DEPTH", 3 if wl["grid"] <= 256 else 2)), 1)
 
@@ -776,8 +776,8 @@ def main(argv=None):
                 rf.update(ex)
                 if cpu is not None and name + "_cpu_steps_per_s" in ex:
                     cpu[name + "_value"] = ex[name + "_cpu_steps_per_s"]
-            rf["extras_note"] = ("cN_steps_per_s / cN_ms / cN_frac: whole jobs with two in flight (8 timed after 4 untimed, host clock "
-                                 "between syncs; the faster of the two_jobs and walk_train regimes, cN_regime), frac = 16 B x photon-steps / ms / 8 TB/s; cN_one_launch_*: one lt_launch alone with the "
+            rf["extras_note"] = ("cN_steps_per_s / cN_ms / cN_frac: whole jobs with two or three in flight (8 / 12 timed after 4 / 6 untimed, host clock "
+                                 "between syncs; the fastest of the two_jobs, walk_train and (256^3 grids) three_jobs regimes, cN_regime), frac = 16 B x photon-steps / ms / 8 TB/s; cN_one_launch_*: one lt_launch alone with the "
                                  "library's defaults (mean of 3, device time); cN_alone_*: that launch's kernels on one lane with nothing "
                                  "beside them; cN_cpu_steps_per_s: the CPU oracle on cN_cpu_cores threads, a ~3 s sample")
         print(json.dumps(out))
