@@ -287,7 +287,7 @@ def measure_extra(name, make_ctx, args, cpu_seconds):
         if wl["grid"] <= 256:
             add_ctx()
             jobs(6, 760)
-            ms_3, steps_3 = jobs(12, 770)
+            ms_3, steps_3 = jobs(18, 770)
             both[name + "_three_jobs_ms"] = ms_3
             if ms_3 < ms:
                 ms, steps, regime = ms_3, steps_3, "three_jobs"
@@ -776,7 +776,7 @@ def main(argv=None):
                 rf.update(ex)
                 if cpu is not None and name + "_cpu_steps_per_s" in ex:
                     cpu[name + "_value"] = ex[name + "_cpu_steps_per_s"]
-            rf["extras_note"] = ("cN_steps_per_s / cN_ms / cN_frac: whole jobs with two or three in flight (8 / 12 timed after 4 / 6 untimed, host clock "
+            rf["extras_note"] = ("cN_steps_per_s / cN_ms / cN_frac: whole jobs with two or three in flight (8 / 18 timed after 4 / 6 untimed, host clock "
                                  "between syncs; the fastest of the two_jobs, walk_train and (256^3 grids) three_jobs regimes, cN_regime), frac = 16 B x photon-steps / ms / 8 TB/s; cN_one_launch_*: one lt_launch alone with the "
                                  "library's defaults (mean of 3, device time); cN_alone_*: that launch's kernels on one lane with nothing "
                                  "beside them; cN_cpu_steps_per_s: the CPU oracle on cN_cpu_cores threads, a ~3 s sample")
