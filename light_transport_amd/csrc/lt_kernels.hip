@@ -145,51 +145,111 @@ LT_DEV double rsqrt_pos(double x)                        // 1 / sqrt(x), x > 0 w
     e = __builtin_fma(-(x * y), y, 1.0);
     return __builtin_fma(0.5 * y, e, y);
 }
-LT_DEV double neg_log_unit(double x)                     // -ln(x), x in [2^-53, 1]
+// -ln(x) and sin / cos(2 pi x) of the step (free path, azimuth) by TABLE + SHORT POLYNOMIAL: a step spends 17 instructions
+// less on the azimuth and a dozen less on the logarithm than with the table-free forms they replace (two degree-7 / 8
+// polynomials + a quadrant rotation by selects; a quotient + a ten-term series).  kWalkMathTab: 97 x {1 / j, ln(j / 128)},
+// j = 96..192, then 64 x {sin, cos}(2 pi i / 64) -- correctly rounded values, 2576 bytes; the walk kernels stage them in LDS
+// (one 16-byte read per use), the per-function kernel reads them from global memory.  Accuracy as before: 2.5e-16 relative
+// for the logarithm (the cell around m = 1 has ln c = 0 and r = m - 1 exactly, so -ln x -> 1 - x keeps its relative accuracy),
+// 1.2e-16 absolute for sin / cos; exact at the quarter turns.
+__device__ const double kWalkMathTab[(97 + 64) * 2] = {
+    // {1 / j, ln(j / 128)}, j = 96 .. 192
+    0x1.5555555555555p-7, -0x1.269621134db92p-2, 0x1.51d07eae2f815p-7, -0x1.1bf99635a6b95p-2, 0x1.4e5e0a72f0539p-7, -0x1.1178e8227e47cp-2,
+    0x1.4afd6a052bf5bp-7, -0x1.07138604d5862p-2, 0x1.47ae147ae147bp-7, -0x1.f991c6cb3b379p-3, 0x1.446f86562d9fbp-7, -0x1.e530effe71012p-3,
+    0x1.4141414141414p-7, -0x1.d1037f2655e7bp-3, 0x1.3e22cbce4a902p-7, -0x1.bd087383bd8adp-3, 0x1.3b13b13b13b14p-7, -0x1.a93ed3c8ad9e3p-3,
+    0x1.3813813813814p-7, -0x1.95a5adcf7017fp-3, 0x1.3521cfb2b78c1p-7, -0x1.823c16551a3c2p-3, 0x1.323e34a2b10bfp-7, -0x1.6f0128b756abcp-3,
+    0x1.2f684bda12f68p-7, -0x1.5bf406b543db2p-3, 0x1.2c9fb4d812ca0p-7, -0x1.4913d8333b561p-3, 0x1.29e4129e4129ep-7, -0x1.365fcb0159016p-3,
+    0x1.27350b8812735p-7, -0x1.23d712a49c202p-3, 0x1.2492492492492p-7, -0x1.1178e8227e47cp-3, 0x1.21fb78121fb78p-7, -0x1.fe89139dbd566p-4,
+    0x1.1f7047dc11f70p-7, -0x1.da727638446a2p-4, 0x1.1cf06ada2811dp-7, -0x1.b6ac88dad5b1cp-4, 0x1.1a7b9611a7b96p-7, -0x1.9335e5d594989p-4,
+    0x1.1811811811812p-7, -0x1.700d30aeac0e1p-4, 0x1.15b1e5f75270dp-7, -0x1.4d3115d207eacp-4, 0x1.135c81135c811p-7, -0x1.2aa04a44717a5p-4,
+    0x1.1111111111111p-7, -0x1.08598b59e3a07p-4, 0x1.0ecf56be69c90p-7, -0x1.ccb73cdddb2ccp-5, 0x1.0c9714fbcda3bp-7, -0x1.894aa149fb343p-5,
+    0x1.0a6810a6810a7p-7, -0x1.466aed42de3eap-5, 0x1.0842108421084p-7, -0x1.0415d89e74444p-5, 0x1.0624dd2f1a9fcp-7, -0x1.8492528c8cabfp-6,
+    0x1.0410410410410p-7, -0x1.0205658935847p-6, 0x1.0204081020408p-7, -0x1.010157588de71p-7, 0x1.0000000000000p-7, 0x0.0p+0,
+    0x1.fc07f01fc07f0p-8, 0x1.fe02a6b106789p-8, 0x1.f81f81f81f820p-8, 0x1.fc0a8b0fc03e4p-7, 0x1.f44659e4a4271p-8, 0x1.7b91b07d5b11bp-6,
+    0x1.f07c1f07c1f08p-8, 0x1.f829b0e783300p-6, 0x1.ecc07b301ecc0p-8, 0x1.39e87b9febd60p-5, 0x1.e9131abf0b767p-8, 0x1.77458f632dcfcp-5,
+    0x1.e573ac901e574p-8, 0x1.b42dd711971bfp-5, 0x1.e1e1e1e1e1e1ep-8, 0x1.f0a30c01162a6p-5, 0x1.de5d6e3f8868ap-8, 0x1.16536eea37ae1p-4,
+    0x1.dae6076b981dbp-8, 0x1.341d7961bd1d1p-4, 0x1.d77b654b82c34p-8, 0x1.51b073f06183fp-4, 0x1.d41d41d41d41dp-8, 0x1.6f0d28ae56b4cp-4,
+    0x1.d0cb58f6ec074p-8, 0x1.8c345d6319b21p-4, 0x1.cd85689039b0bp-8, 0x1.a926d3a4ad563p-4, 0x1.ca4b3055ee191p-8, 0x1.c5e548f5bc743p-4,
+    0x1.c71c71c71c71cp-8, 0x1.e27076e2af2e6p-4, 0x1.c3f8f01c3f8f0p-8, 0x1.fec9131dbeabbp-4, 0x1.c0e070381c0e0p-8, 0x1.0d77e7cd08e59p-3,
+    0x1.bdd2b899406f7p-8, 0x1.1b72ad52f67a0p-3, 0x1.bacf914c1bad0p-8, 0x1.29552f81ff523p-3, 0x1.b7d6c3dda338bp-8, 0x1.371fc201e8f74p-3,
+    0x1.b4e81b4e81b4fp-8, 0x1.44d2b6ccb7d1ep-3, 0x1.b2036406c80d9p-8, 0x1.526e5e3a1b438p-3, 0x1.af286bca1af28p-8, 0x1.5ff3070a793d4p-3,
+    0x1.ac5701ac5701bp-8, 0x1.6d60fe719d21dp-3, 0x1.a98ef606a63bep-8, 0x1.7ab890210d909p-3, 0x1.a6d01a6d01a6dp-8, 0x1.87fa06520c911p-3,
+    0x1.a41a41a41a41ap-8, 0x1.9525a9cf456b4p-3, 0x1.a16d3f97a4b02p-8, 0x1.a23bc1fe2b563p-3, 0x1.9ec8e951033d9p-8, 0x1.af3c94e80bff3p-3,
+    0x1.9c2d14ee4a102p-8, 0x1.bc286742d8cd6p-3, 0x1.999999999999ap-8, 0x1.c8ff7c79a9a22p-3, 0x1.970e4f80cb872p-8, 0x1.d5c216b4fbb91p-3,
+    0x1.948b0fcd6e9e0p-8, 0x1.e27076e2af2e6p-3, 0x1.920fb49d0e229p-8, 0x1.ef0adcbdc5936p-3, 0x1.8f9c18f9c18fap-8, 0x1.fb9186d5e3e2bp-3,
+    0x1.8d3018d3018d3p-8, 0x1.0402594b4d041p-2, 0x1.8acb90f6bf3aap-8, 0x1.0a324e27390e3p-2, 0x1.886e5f0abb04ap-8, 0x1.1058bf9ae4ad5p-2,
+    0x1.8618618618618p-8, 0x1.1675cababa60ep-2, 0x1.83c977ab2beddp-8, 0x1.1c898c16999fbp-2, 0x1.8181818181818p-8, 0x1.22941fbcf7966p-2,
+    0x1.7f405fd017f40p-8, 0x1.2895a13de86a3p-2, 0x1.7d05f417d05f4p-8, 0x1.2e8e2bae11d31p-2, 0x1.7ad2208e0ecc3p-8, 0x1.347dd9a987d55p-2,
+    0x1.78a4c8178a4c8p-8, 0x1.3a64c556945eap-2, 0x1.767dce434a9b1p-8, 0x1.404308686a7e4p-2, 0x1.745d1745d1746p-8, 0x1.4618bc21c5ec2p-2,
+    0x1.724287f46debcp-8, 0x1.4be5f957778a1p-2, 0x1.702e05c0b8170p-8, 0x1.51aad872df82dp-2, 0x1.6e1f76b4337c7p-8, 0x1.5767717455a6cp-2,
+    0x1.6c16c16c16c17p-8, 0x1.5d1bdbf5809cap-2, 0x1.6a13cd1537290p-8, 0x1.62c82f2b9c795p-2, 0x1.6816816816817p-8, 0x1.686c81e9b14afp-2,
+    0x1.661ec6a5122f9p-8, 0x1.6e08eaa2ba1e4p-2, 0x1.642c8590b2164p-8, 0x1.739d7f6bbd007p-2, 0x1.623fa77016240p-8, 0x1.792a55fdd47a2p-2,
+    0x1.6058160581606p-8, 0x1.7eaf83b82afc3p-2, 0x1.5e75bb8d015e7p-8, 0x1.842d1da1e8b17p-2, 0x1.5c9882b931057p-8, 0x1.89a3386c1425bp-2,
+    0x1.5ac056b015ac0p-8, 0x1.8f11e873662c7p-2, 0x1.58ed2308158edp-8, 0x1.947941c2116fbp-2, 0x1.571ed3c506b3ap-8, 0x1.99d958117e08bp-2,
+    0x1.5555555555555p-8, 0x1.9f323ecbf984cp-2,
+    // {sin, cos}(2 pi i / 64), i = 0 .. 63
+    0x0.0p+0, 0x1.0000000000000p+0, 0x1.917a6bc29b42cp-4, 0x1.fd88da3d12526p-1, 0x1.8f8b83c69a60bp-3, 0x1.f6297cff75cb0p-1,
+    0x1.294062ed59f06p-2, 0x1.e9f4156c62ddap-1, 0x1.87de2a6aea963p-2, 0x1.d906bcf328d46p-1, 0x1.e2b5d3806f63bp-2, 0x1.c38b2f180bdb1p-1,
+    0x1.1c73b39ae68c8p-1, 0x1.a9b66290ea1a3p-1, 0x1.44cf325091dd6p-1, 0x1.8bc806b151741p-1, 0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1,
+    0x1.8bc806b151741p-1, 0x1.44cf325091dd6p-1, 0x1.a9b66290ea1a3p-1, 0x1.1c73b39ae68c8p-1, 0x1.c38b2f180bdb1p-1, 0x1.e2b5d3806f63bp-2,
+    0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2, 0x1.e9f4156c62ddap-1, 0x1.294062ed59f06p-2, 0x1.f6297cff75cb0p-1, 0x1.8f8b83c69a60bp-3,
+    0x1.fd88da3d12526p-1, 0x1.917a6bc29b42cp-4, 0x1.0000000000000p+0, 0x0.0p+0, 0x1.fd88da3d12526p-1, -0x1.917a6bc29b42cp-4,
+    0x1.f6297cff75cb0p-1, -0x1.8f8b83c69a60bp-3, 0x1.e9f4156c62ddap-1, -0x1.294062ed59f06p-2, 0x1.d906bcf328d46p-1, -0x1.87de2a6aea963p-2,
+    0x1.c38b2f180bdb1p-1, -0x1.e2b5d3806f63bp-2, 0x1.a9b66290ea1a3p-1, -0x1.1c73b39ae68c8p-1, 0x1.8bc806b151741p-1, -0x1.44cf325091dd6p-1,
+    0x1.6a09e667f3bcdp-1, -0x1.6a09e667f3bcdp-1, 0x1.44cf325091dd6p-1, -0x1.8bc806b151741p-1, 0x1.1c73b39ae68c8p-1, -0x1.a9b66290ea1a3p-1,
+    0x1.e2b5d3806f63bp-2, -0x1.c38b2f180bdb1p-1, 0x1.87de2a6aea963p-2, -0x1.d906bcf328d46p-1, 0x1.294062ed59f06p-2, -0x1.e9f4156c62ddap-1,
+    0x1.8f8b83c69a60bp-3, -0x1.f6297cff75cb0p-1, 0x1.917a6bc29b42cp-4, -0x1.fd88da3d12526p-1, 0x0.0p+0, -0x1.0000000000000p+0,
+    -0x1.917a6bc29b42cp-4, -0x1.fd88da3d12526p-1, -0x1.8f8b83c69a60bp-3, -0x1.f6297cff75cb0p-1, -0x1.294062ed59f06p-2, -0x1.e9f4156c62ddap-1,
+    -0x1.87de2a6aea963p-2, -0x1.d906bcf328d46p-1, -0x1.e2b5d3806f63bp-2, -0x1.c38b2f180bdb1p-1, -0x1.1c73b39ae68c8p-1, -0x1.a9b66290ea1a3p-1,
+    -0x1.44cf325091dd6p-1, -0x1.8bc806b151741p-1, -0x1.6a09e667f3bcdp-1, -0x1.6a09e667f3bcdp-1, -0x1.8bc806b151741p-1, -0x1.44cf325091dd6p-1,
+    -0x1.a9b66290ea1a3p-1, -0x1.1c73b39ae68c8p-1, -0x1.c38b2f180bdb1p-1, -0x1.e2b5d3806f63bp-2, -0x1.d906bcf328d46p-1, -0x1.87de2a6aea963p-2,
+    -0x1.e9f4156c62ddap-1, -0x1.294062ed59f06p-2, -0x1.f6297cff75cb0p-1, -0x1.8f8b83c69a60bp-3, -0x1.fd88da3d12526p-1, -0x1.917a6bc29b42cp-4,
+    -0x1.0000000000000p+0, 0x0.0p+0, -0x1.fd88da3d12526p-1, 0x1.917a6bc29b42cp-4, -0x1.f6297cff75cb0p-1, 0x1.8f8b83c69a60bp-3,
+    -0x1.e9f4156c62ddap-1, 0x1.294062ed59f06p-2, -0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2, -0x1.c38b2f180bdb1p-1, 0x1.e2b5d3806f63bp-2,
+    -0x1.a9b66290ea1a3p-1, 0x1.1c73b39ae68c8p-1, -0x1.8bc806b151741p-1, 0x1.44cf325091dd6p-1, -0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1,
+    -0x1.44cf325091dd6p-1, 0x1.8bc806b151741p-1, -0x1.1c73b39ae68c8p-1, 0x1.a9b66290ea1a3p-1, -0x1.e2b5d3806f63bp-2, 0x1.c38b2f180bdb1p-1,
+    -0x1.87de2a6aea963p-2, 0x1.d906bcf328d46p-1, -0x1.294062ed59f06p-2, 0x1.e9f4156c62ddap-1, -0x1.8f8b83c69a60bp-3, 0x1.f6297cff75cb0p-1,
+    -0x1.917a6bc29b42cp-4, 0x1.fd88da3d12526p-1
+};
+constexpr int kLnTabEntries = 97, kScTabEntries = 64;
+constexpr size_t kWalkMathTabBytes = sizeof(double) * 2 * (kLnTabEntries + kScTabEntries);
+LT_DEV double neg_log_tab(double x, const double* T)     // -ln(x), x in [2^-53, 1]; T = kWalkMathTab (global or its LDS copy)
 {
     int e = __builtin_amdgcn_frexp_exp(x);
     double m = __builtin_amdgcn_frexp_mant(x);           // [0.5, 1)
-    if (m < 0.70710678118654752) { m += m; e -= 1; }     // -> [sqrt(1/2), sqrt(2))
-    const double f = m - 1.0;
-    const double s = fast_div(f, 2.0 + f);               // (m - 1) / (m + 1), |s| <= 0.1716
-    const double z = s * s;
-    // ln(m) = 2 s (1 + z/3 + z^2/5 + ... + z^10/21); the truncated tail is < 3e-18 relative
-    double p = 1.0 / 21.0;
-    p = fma_k(p, z, 1.0 / 19.0); p = fma_k(p, z, 1.0 / 17.0); p = fma_k(p, z, 1.0 / 15.0);
-    p = fma_k(p, z, 1.0 / 13.0); p = fma_k(p, z, 1.0 / 11.0); p = fma_k(p, z, 1.0 / 9.0);
-    p = fma_k(p, z, 1.0 / 7.0);  p = fma_k(p, z, 1.0 / 5.0);  p = fma_k(p, z, 1.0 / 3.0);
-    const double lnm = __builtin_fma(2.0 * s * z, p, 2.0 * s);
+    if (m < 0.75) { m += m; e -= 1; }                    // -> [0.75, 1.5)
+    const double t = m * 128.0;                          // exact
+    const double qf = __builtin_rint(t);                 // the cell's centre c = qf / 128, qf = 96 .. 192
+    const double d = t - qf;                             // exact: 128 (m - c)
+    const double2 Tj = *reinterpret_cast<const double2*>(T + 2 * ((int)qf - 96));
+    const double r = d * Tj.x;                           // (m - c) / c, |r| <= 1 / 192
+    // ln(1 + r) = r - r^2/2 + ... + r^7/7; the truncated tail is < 2e-18 relative to r
+    double p = 1.0 / 7.0;
+    p = fma_k(p, r, -1.0 / 6.0); p = fma_k(p, r, 1.0 / 5.0); p = fma_k(p, r, -0.25); p = fma_k(p, r, 1.0 / 3.0);
+    p = __builtin_fma(p, r, -0.5);
+    const double lnm = Tj.y + __builtin_fma(r * r, p, r);
     const double de = (double)e;
     // ln 2 split so that e * hi is exact for |e| <= 53
     return -fma_mk(de, 6.93147180369123816490e-01, fma_mk(de, 1.90821492927058770002e-10, lnm));
 }
-LT_DEV void sincos_turn_f64(double xi, double* sn, double* cs)  // sin, cos of 2*pi*xi, xi in (0, 1]
+LT_DEV void sincos_turn_tab(double xi, const double* T, double* sn, double* cs)  // sin, cos of 2*pi*xi, xi in (0, 1]; T = kWalkMathTab
 {
-    const double t = 4.0 * xi;                           // exact
+    const double t = 64.0 * xi;                          // exact
     const double qf = __builtin_rint(t);
-    const double a = mul_k(t - qf, 1.57079632679489661923);  // (t - qf) exact, |a| <= pi/4
+    const double a = mul_k(t - qf, 9.8174770424681038702e-02);   // (t - qf) exact; 2 pi / 64; |a| <= pi / 64
     const double z = a * a;
-    double ps = -7.6471637318198164759e-13;              // -1/15!
-    ps = fma_k(ps, z, 1.6059043836821614599e-10);   //  1/13!
-    ps = fma_k(ps, z, -2.5052108385441718775e-08);  // -1/11!
-    ps = fma_k(ps, z, 2.7557319223985890653e-06);   //  1/9!
-    ps = fma_k(ps, z, -1.9841269841269841270e-04);  // -1/7!
+    double ps = -1.9841269841269841270e-04;              // -1/7!   (tail a^9 / 9! < 5e-18)
     ps = fma_k(ps, z, 8.3333333333333333333e-03);   //  1/5!
     ps = fma_k(ps, z, -1.6666666666666666667e-01);  // -1/3!
-    const double s = __builtin_fma(a * z, ps, a);
-    double pc = 4.7794773323873852974e-14;               //  1/16!
-    pc = fma_k(pc, z, -1.1470745597729724714e-11);  // -1/14!
-    pc = fma_k(pc, z, 2.0876756987868098979e-09);   //  1/12!
-    pc = fma_k(pc, z, -2.7557319223985890653e-07);  // -1/10!
-    pc = fma_k(pc, z, 2.4801587301587301587e-05);   //  1/8!
+    const double sd = __builtin_fma(a * z, ps, a);
+    double pc = 2.4801587301587301587e-05;               //  1/8!   (tail z^5 / 10! < 1e-20)
     pc = fma_k(pc, z, -1.3888888888888888889e-03);  // -1/6!
     pc = fma_k(pc, z, 4.1666666666666666667e-02);   //  1/4!
     pc = __builtin_fma(pc, z, -0.5);
-    const double c = __builtin_fma(pc, z, 1.0);
-    const int q = (int)qf & 3;                           // quadrant rotation
-    const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
-    *sn = (q & 2) ? -s1 : s1;
-    *cs = ((q + 1) & 2) ? -c1 : c1;
+    const double cd = __builtin_fma(pc, z, 1.0);
+    const double2 Ti = *reinterpret_cast<const double2*>(T + 2 * (kLnTabEntries + ((int)qf & (kScTabEntries - 1))));
+    *sn = __builtin_fma(Ti.x, cd, Ti.y * sd);            // angle addition: the cell's sin / cos turned by the remainder
+    *cs = __builtin_fma(Ti.y, cd, -(Ti.x * sd));
 }
 
 // sin, cos of x for |x| <= pi (the renderers' concentric disk map: theta in [-pi/4, 3 pi/4]): reduction by multiples of pi/2
@@ -233,12 +293,12 @@ template <> struct Mx<double> {
     static LT_DEV double sin(double x) { return ::sin(x); }
     static LT_DEV double cos(double x) { return ::cos(x); }
     // the hot-loop forms (restricted ranges, see above)
-    static LT_DEV double neg_log(double xi) { return neg_log_unit(xi); }
+    static LT_DEV double neg_log(double xi, const double* T) { return neg_log_tab(xi, T); }
     static LT_DEV double sqrt_unit(double x) { return sqrt01(x); }
     static LT_DEV double sqrt_pos(double x) { return ltk::sqrt_pos(x); }
     static LT_DEV double rsqrt_pos(double x) { return ltk::rsqrt_pos(x); }
     static LT_DEV double quot(double a, double b) { return fast_div(a, b); }
-    static LT_DEV void sincos_turn(double xi, double* s, double* c) { sincos_turn_f64(xi, s, c); }
+    static LT_DEV void sincos_turn(double xi, const double* T, double* s, double* c) { sincos_turn_tab(xi, T, s, c); }
     static LT_DEV double inf() { return __builtin_huge_val(); }
     // rocrand_uniform_double (rocrand_uniform.h:102-109, 454-460): two draws, 53 bits, (0, 1]
     static LT_DEV double uniform(rocrand_state_xorwow* st)
@@ -257,12 +317,12 @@ template <> struct Mx<float> {
     static LT_DEV float clamp_unit(float c) { return __builtin_fmaxf(__builtin_fminf(c, 1.0f), -1.0f); }
     static LT_DEV float sin(float x) { return ::sinf(x); }
     static LT_DEV float cos(float x) { return ::cosf(x); }
-    static LT_DEV float neg_log(float xi) { return -::logf(xi); }
+    static LT_DEV float neg_log(float xi, const double*) { return -::logf(xi); }
     static LT_DEV float sqrt_unit(float x) { return ::sqrtf(__builtin_fmaxf(x, 0.0f)); }
     static LT_DEV float sqrt_pos(float x) { return ::sqrtf(x); }
     static LT_DEV float rsqrt_pos(float x) { return 1.0f / ::sqrtf(x); }
     static LT_DEV float quot(float a, float b) { return a / b; }
-    static LT_DEV void sincos_turn(float xi, float* s, float* c) { ::sincospif(2.0f * xi, s, c); }
+    static LT_DEV void sincos_turn(float xi, const double*, float* s, float* c) { ::sincospif(2.0f * xi, s, c); }
     static LT_DEV float inf() { return __builtin_huge_valf(); }
     static LT_DEV float uniform(rocrand_state_xorwow* st) { return rocrand_uniform(st); }
     static LT_DEV float uniform32(rocrand_state_xorwow* st) { return rocrand_uniform(st); }
@@ -916,11 +976,11 @@ template <typename R> LT_DEV R boundary_planar(R uz, R n1, R n2, R Nr, R* cos_t_
 }
 
 // Spin (App. C.6): MCML direction update, |uz| > 0.99999 special case.
-template <typename R> LT_DEV void spin(R* u, R ct, R xi_phi)
+template <typename R> LT_DEV void spin(R* u, R ct, R xi_phi, const double* T)      // T: kWalkMathTab or its LDS copy (f64 walks)
 {
     R st2 = (R)1 - ct * ct;
     R st = Mx<R>::sqrt_unit(st2);                       // clamps a rounding-negative 1 - ct^2 to 0 itself
-    R sp, cp; Mx<R>::sincos_turn(xi_phi, &sp, &cp);
+    R sp, cp; Mx<R>::sincos_turn(xi_phi, T, &sp, &cp);
     R ux = u[0], uy = u[1], uz = u[2];
     if (Mx<R>::abs(uz) > (R)0.99999) {
         u[0] = st * cp; u[1] = st * sp; u[2] = uz >= 0 ? ct : -ct;
@@ -991,7 +1051,7 @@ template <int TALLY> LT_DEV void tally_add(void* grid, unsigned idx, typename Ta
 LT_DEV size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 template <typename R> struct LdsLayout {
-    size_t off_cnt, off_frame, off_media, off_zb, off_if, off_lm, off_tris, off_nodes, off_links, off_hist, off_march, total;
+    size_t off_cnt, off_frame, off_media, off_zb, off_if, off_lm, off_tris, off_nodes, off_links, off_hist, off_march, off_math, total;
     __host__ __device__ LdsLayout(int n_media, int n_layers, int n_tris, int n_nodes, unsigned n_hist = 0, size_t march_bytes = 0)
     {
         auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -1007,6 +1067,7 @@ template <typename R> struct LdsLayout {
         off_links = o; o = al(o + (size_t)n_nodes * 16 * sizeof(int16_t));      // front-to-back link tables (8 patterns x first | after)
         off_hist = o;  o = al(o + (size_t)n_hist * sizeof(uint32_t));
         off_march = o; o = al(o + march_bytes);
+        off_math = o;  o = al(o + (sizeof(R) == 8 ? kWalkMathTabBytes : 0));      // f64 walks: kWalkMathTab
         total = o;
     }
 };
@@ -1416,13 +1477,13 @@ __global__ void k_eval(int fn, const double* in, size_t n, double* out)
     } break;
     case LT_FN_SPIN: {
         double u[3] = {in[5 * i], in[5 * i + 1], in[5 * i + 2]};
-        spin(u, in[5 * i + 3], in[5 * i + 4]);
+        spin(u, in[5 * i + 3], in[5 * i + 4], kWalkMathTab);
         for (int k = 0; k < 3; k++) out[3 * i + k] = u[k];
     } break;
     case LT_FN_WALK_MATH: {   // the walk's lean f64 primitives: -ln x, sin/cos(2 pi x), sqrt x, 1 / (1 + x)
         const double x = in[i];
-        out[5 * i] = neg_log_unit(x);
-        sincos_turn_f64(x, &out[5 * i + 1], &out[5 * i + 2]);
+        out[5 * i] = neg_log_tab(x, kWalkMathTab);
+        sincos_turn_tab(x, kWalkMathTab, &out[5 * i + 1], &out[5 * i + 2]);
         out[5 * i + 3] = sqrt01(x);
         out[5 * i + 4] = fast_div(1.0, 1.0 + x);
     } break;
