@@ -107,25 +107,19 @@ template <unsigned long long BITS> LT_DEV double fma_kkb(double x)
 }
 #define fma_kk(x, k) fma_kkb<__builtin_bit_cast(unsigned long long, (double)(k))>((x))
 #endif
-LT_DEV double fast_rcp(double d)
-{
-    double r = __builtin_amdgcn_rcp(d);                 // v_rcp_f64: ~26 good bits
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-    return r;
-}
 LT_DEV double fast_div(double a, double b)
 {
-    const double r = fast_rcp(b);
+    // ONE Newton step on the seed (-> ~52 bits) is enough here: the residual correction below squares the error once more
+    double r = __builtin_amdgcn_rcp(b);                 // v_rcp_f64: ~26 good bits
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
     const double q = a * r;
     return __builtin_fma(__builtin_fma(-b, q, a), r, q); // one residual correction
 }
 LT_DEV double sqrt_core(double x, double y)              // y ~ 1/sqrt(x) to ~26 bits (v_rsq_f64)
 {
+    // one coupled Newton round (26 -> ~52 bits), then the residual step squares the error again: correctly rounded but for rare ties
     double g = x * y, h = 0.5 * y;
-    double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
-    r = __builtin_fma(-h, g, 0.5);
+    const double r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
     const double d = __builtin_fma(-g, g, x);
     return __builtin_fma(d, h, g);
