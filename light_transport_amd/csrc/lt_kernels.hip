@@ -538,10 +538,16 @@ template <typename R> LT_DEV bool plane_within_reach(const TriD<R>* T, R px, R p
 template <typename R, bool TABLE> struct HeldU {
     typedef R type;
     static LT_DEV R get(R v) { return v; }
+    static LT_DEV R draw(rocrand_state_xorwow* st) { return Mx<R>::uniform32(st); }
+    static LT_DEV R as_real(R v) { return v; }
+    static LT_DEV R from_real(R v) { return v; }
 };
 template <> struct HeldU<double, false> {
     typedef unsigned type;
     static LT_DEV double get(unsigned v) { return fma_kk((double)v, 2.3283064365386962891e-10); }     // Mx<double>::uniform32
+    static LT_DEV unsigned draw(rocrand_state_xorwow* st) { return rocrand(st); }
+    static LT_DEV double as_real(unsigned v) { return (double)v; }       // (exact both ways: the march kernel parks it in an LDS array of R)
+    static LT_DEV unsigned from_real(double v) { return (unsigned)v; }
 };
 
 // c0 of the cell that holds (px, py, pz): -1 outside the grid (always query)
@@ -979,11 +985,16 @@ template <typename R> LT_DEV void spin(R* u, R ct, R xi_phi, const double* T)   
     if (Mx<R>::abs(uz) > (R)0.99999) {
         u[0] = st * cp; u[1] = st * sp; u[2] = uz >= 0 ? ct : -ct;
     } else {
-        R t2 = (R)1 - uz * uz;                          // |uz| <= 0.99999: t2 >= 2e-5
-        R inv = Mx<R>::rsqrt_pos(t2), tmp = t2 * inv;   // 1 / sqrt(t2) once; the two quotients become products
-        u[0] = st * (ux * uz * cp - uy * sp) * inv + ux * ct;
-        u[1] = st * (uy * uz * cp + ux * sp) * inv + uy * ct;
-        u[2] = -st * cp * tmp + uz * ct;
+        // MCML's update with A = sin(theta) / sqrt(1 - uz^2) factored out (10 products / fused products instead of 17):
+        //   ux' = ux (uz A cos(phi) + cos(theta)) - uy A sin(phi),   uy' = uy (...) + ux A sin(phi),
+        //   uz' = uz cos(theta) - A cos(phi) (1 - uz^2)
+        const R t2 = (R)1 - uz * uz;                    // |uz| <= 0.99999: t2 >= 2e-5
+        const R a = st * Mx<R>::rsqrt_pos(t2);          // 1 / sqrt(t2) once; the quotients become products
+        const R sc = a * cp, ss = a * sp;
+        const R k = uz * sc + ct;
+        u[0] = ux * k - uy * ss;
+        u[1] = uy * k + ux * ss;
+        u[2] = uz * ct - sc * t2;
     }
 }
 
