@@ -227,6 +227,7 @@ void fill_media(const std::vector<lt_medium>& in, int quantity, std::vector<MedD
         m.one_p_g2 = (R)1 + g * g;
         m.inv_2g = g != 0 ? (R)1 / ((R)2 * g) : (R)0;
         m.dep = quantity == LT_QUANTITY_FLUENCE ? m.inv_mu_t : m.absorb;
+        m.one_m_g = (R)1 - g; m.two_g = (R)2 * g;
         m.pad_ = 0;
     }
 }

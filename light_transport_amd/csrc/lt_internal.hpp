@@ -15,6 +15,7 @@ struct MedD {
     R mu_t, inv_mu_t, absorb, g;
     R n, one_m_g2, one_p_g2, inv_2g;
     R dep;   // what a voxel receives per unit of photon weight at an interaction: absorb, or inv_mu_t (LT_QUANTITY_FLUENCE)
+    R one_m_g, two_g;   // the walk's Henyey-Greenstein denominator: (1 - g) + (2 g) xi as one fused product
     R pad_;
 };
 

@@ -850,6 +850,15 @@ template <typename R> LT_DEV R hg_sample(R xi, R g, R one_m_g2, R one_p_g2, R in
     return Mx<R>::clamp_unit(c);   // [-1, 1]
 }
 
+// ... as the walk takes it: the denominator from the medium record ((1 - g) + (2 g) xi, one fused product) and NO clamp -- the
+// value leaves [-1, 1] by a rounding at most, which sqrt01 (sin theta) absorbs and the direction update does not notice.
+template <typename R> LT_DEV R hg_sample_walk(R xi, const MedD<R>* M)
+{
+    if (M->g == 0) return (R)2 * xi - (R)1;
+    const R t = Mx<R>::quot(M->one_m_g2, M->two_g * xi + M->one_m_g);
+    return (M->one_p_g2 - t * t) * M->inv_2g;
+}
+
 // create_orthonormal_system, S/utils.py:72-80
 template <typename R> LT_DEV void onb(const R* n, R* v2, R* v3)
 {
