@@ -289,6 +289,8 @@ template <> struct Mx<double> {
     // the hot-loop forms (restricted ranges, see above)
     static LT_DEV double neg_log(double xi, const double* T) { return neg_log_tab(xi, T); }
     static LT_DEV double sqrt_unit(double x) { return sqrt01(x); }
+    static LT_DEV double max0(double x) { return __builtin_fmax(x, 0.0); }
+    static LT_DEV double max_tiny(double x) { return __builtin_fmax(x, 1e-300); }
     static LT_DEV double sqrt_pos(double x) { return ltk::sqrt_pos(x); }
     static LT_DEV double rsqrt_pos(double x) { return ltk::rsqrt_pos(x); }
     static LT_DEV double quot(double a, double b) { return fast_div(a, b); }
@@ -313,6 +315,8 @@ template <> struct Mx<float> {
     static LT_DEV float cos(float x) { return ::cosf(x); }
     static LT_DEV float neg_log(float xi, const double*) { return -::logf(xi); }
     static LT_DEV float sqrt_unit(float x) { return ::sqrtf(__builtin_fmaxf(x, 0.0f)); }
+    static LT_DEV float max0(float x) { return __builtin_fmaxf(x, 0.0f); }
+    static LT_DEV float max_tiny(float x) { return __builtin_fmaxf(x, 1e-30f); }
     static LT_DEV float sqrt_pos(float x) { return ::sqrtf(x); }
     static LT_DEV float rsqrt_pos(float x) { return 1.0f / ::sqrtf(x); }
     static LT_DEV float quot(float a, float b) { return a / b; }
@@ -987,18 +991,19 @@ template <typename R> LT_DEV R boundary_planar(R uz, R n1, R n2, R Nr, R* cos_t_
 // Spin (App. C.6): MCML direction update, |uz| > 0.99999 special case.
 template <typename R> LT_DEV void spin(R* u, R ct, R xi_phi, const double* T)      // T: kWalkMathTab or its LDS copy (f64 walks)
 {
-    R st2 = (R)1 - ct * ct;
-    R st = Mx<R>::sqrt_unit(st2);                       // clamps a rounding-negative 1 - ct^2 to 0 itself
+    const R st2 = Mx<R>::max0((R)1 - ct * ct);          // sin^2(theta); a rounding-negative value is 0
     R sp, cp; Mx<R>::sincos_turn(xi_phi, T, &sp, &cp);
     R ux = u[0], uy = u[1], uz = u[2];
     if (Mx<R>::abs(uz) > (R)0.99999) {
+        const R st = Mx<R>::sqrt_unit(st2);
         u[0] = st * cp; u[1] = st * sp; u[2] = uz >= 0 ? ct : -ct;
     } else {
         // MCML's update with A = sin(theta) / sqrt(1 - uz^2) factored out (10 products / fused products instead of 17):
         //   ux' = ux (uz A cos(phi) + cos(theta)) - uy A sin(phi),   uy' = uy (...) + ux A sin(phi),
         //   uz' = uz cos(theta) - A cos(phi) (1 - uz^2)
+        // and A from ONE reciprocal root: A = st2 / sqrt(st2 t2) (st2 = 0 gives 0: the seed of 0 is taken at 1e-300)
         const R t2 = (R)1 - uz * uz;                    // |uz| <= 0.99999: t2 >= 2e-5
-        const R a = st * Mx<R>::rsqrt_pos(t2);          // 1 / sqrt(t2) once; the quotients become products
+        const R a = st2 * Mx<R>::rsqrt_pos(Mx<R>::max_tiny(st2 * t2));
         const R sc = a * cp, ss = a * sp;
         const R k = uz * sc + ct;
         u[0] = ux * k - uy * ss;
