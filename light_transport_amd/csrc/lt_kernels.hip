@@ -294,6 +294,7 @@ template <> struct Mx<double> {
     static LT_DEV double sqrt_pos(double x) { return ltk::sqrt_pos(x); }
     static LT_DEV double rsqrt_pos(double x) { return ltk::rsqrt_pos(x); }
     static LT_DEV double quot(double a, double b) { return fast_div(a, b); }
+    static LT_DEV double rcp48(double d) { double r = __builtin_amdgcn_rcp(d); return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r); }      // 1 / d to ~48 bits
     static LT_DEV void sincos_turn(double xi, const double* T, double* s, double* c) { sincos_turn_tab(xi, T, s, c); }
     static LT_DEV double inf() { return __builtin_huge_val(); }
     // rocrand_uniform_double (rocrand_uniform.h:102-109, 454-460): two draws, 53 bits, (0, 1]
@@ -320,6 +321,7 @@ template <> struct Mx<float> {
     static LT_DEV float sqrt_pos(float x) { return ::sqrtf(x); }
     static LT_DEV float rsqrt_pos(float x) { return 1.0f / ::sqrtf(x); }
     static LT_DEV float quot(float a, float b) { return a / b; }
+    static LT_DEV float rcp48(float d) { return 1.0f / d; }
     static LT_DEV void sincos_turn(float xi, const double*, float* s, float* c) { ::sincospif(2.0f * xi, s, c); }
     static LT_DEV float inf() { return __builtin_huge_valf(); }
     static LT_DEV float uniform(rocrand_state_xorwow* st) { return rocrand_uniform(st); }
@@ -959,7 +961,9 @@ template <typename R> LT_DEV R boundary(const R* d, const R* nf, R n1, R n2, R* 
     if (rad <= 0) { *cos_t_out = 0; refr[0] = refr[1] = refr[2] = 0; return 1; }
     R cos_t = Mx<R>::sqrt_pos(rad);
     R a = n1 * cos_i, b = n2 * cos_t, c = n1 * cos_t, e = n2 * cos_i;
-    R rs = Mx<R>::quot(a - b, a + b), rp = Mx<R>::quot(c - e, c + e);
+    const R sab = a + b, sce = c + e;
+    const R rr = Mx<R>::rcp48(sab * sce);               // both amplitude quotients from one reciprocal (see boundary_planar)
+    R rs = (a - b) * sce * rr, rp = (c - e) * sab * rr;
     R k = Nr * cos_i - cos_t;
     refr[0] = d[0] * Nr + nf[0] * k;
     refr[1] = d[1] * Nr + nf[1] * k;
@@ -983,7 +987,11 @@ template <typename R> LT_DEV R boundary_planar(R uz, R n1, R n2, R Nr, R* cos_t_
     if (rad <= 0) { *cos_t_out = 0; return 1; }
     const R cos_t = Mx<R>::sqrt_pos(rad);
     const R a = n1 * cos_i, b = n2 * cos_t, c = n1 * cos_t, e = n2 * cos_i;
-    const R rs = Mx<R>::quot(a - b, a + b), rp = Mx<R>::quot(c - e, c + e);
+    // both amplitude quotients from ONE reciprocal, refined once (~48 bits): the reflectance is only ever compared with a
+    // uniform draw, so 3e-15 of it decides nothing in 1e14 boundary events
+    const R sab = a + b, sce = c + e;
+    const R r = Mx<R>::rcp48(sab * sce);
+    const R rs = (a - b) * sce * r, rp = (c - e) * sab * r;
     *cos_t_out = cos_t;
     return (R)0.5 * (rs * rs + rp * rp);
 }
