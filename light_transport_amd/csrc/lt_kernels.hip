@@ -290,6 +290,7 @@ template <> struct Mx<double> {
     static LT_DEV double neg_log(double xi, const double* T) { return neg_log_tab(xi, T); }
     static LT_DEV double sqrt_unit(double x) { return sqrt01(x); }
     static LT_DEV double max0(double x) { return __builtin_fmax(x, 0.0); }
+    static LT_DEV unsigned sign_word(double x) { return (unsigned)__double2hiint(x); }      // the word that carries the sign bit
     static LT_DEV double max_tiny(double x) { return __builtin_fmax(x, 1e-300); }
     static LT_DEV double sqrt_pos(double x) { return ltk::sqrt_pos(x); }
     static LT_DEV double rsqrt_pos(double x) { return ltk::rsqrt_pos(x); }
@@ -317,6 +318,7 @@ template <> struct Mx<float> {
     static LT_DEV float neg_log(float xi, const double*) { return -::logf(xi); }
     static LT_DEV float sqrt_unit(float x) { return ::sqrtf(__builtin_fmaxf(x, 0.0f)); }
     static LT_DEV float max0(float x) { return __builtin_fmaxf(x, 0.0f); }
+    static LT_DEV unsigned sign_word(float x) { return __float_as_uint(x); }
     static LT_DEV float max_tiny(float x) { return __builtin_fmaxf(x, 1e-30f); }
     static LT_DEV float sqrt_pos(float x) { return ::sqrtf(x); }
     static LT_DEV float rsqrt_pos(float x) { return 1.0f / ::sqrtf(x); }
