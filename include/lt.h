@@ -306,6 +306,7 @@ int lt_intersect_bounds(lt_ctx* ctx, const double* origins, const double* dirs,
 #define LT_FN_BOUNDARY 6
 #define LT_FN_SPIN 7
 #define LT_FN_WALK_MATH 8 /* in: x in (0,1]  out: [5] -ln x, sin 2 pi x, cos 2 pi x, sqrt x, 1/(1+x) -- the walk's f64 primitives */
+#define LT_FN_WALK_MATH_RAW 9 /* in: k = a raw 32-bit draw (as a double)  out: [3] -ln u, sin 2 pi u, cos 2 pi u of u = (k + 1) 2^-32, by the forms the f64 XORWOW walk uses on the raw draw */
 int lt_eval(lt_ctx* ctx, int fn, const double* in, size_t n, double* out);
 /* first `count` raw 32-bit XORWOW outputs of photon `photon_id` under `seed`
  * (checks the per-photon seeding against the oracle's restatement) */

@@ -17,8 +17,8 @@ TALLY_NP = {0: np.float32, 1: np.float64, 2: np.uint64}
 FX_SCALE = 2.0 ** 40
 SRC_PENCIL, SRC_COSINE_QUAD = 0, 1
 FLAG_F32_WALK = 1
-FN = dict(HG_PDF=0, HG_SAMPLE=1, ONB=2, DISK=3, COSINE_HEMI=4, REFLECT=5, BOUNDARY=6, SPIN=7, WALK_MATH=8)
-_FN_SHAPE = {0: (2, 1), 1: (2, 1), 2: (3, 6), 3: (2, 2), 4: (8, 4), 5: (6, 3), 6: (8, 5), 7: (5, 3), 8: (1, 5)}
+FN = dict(HG_PDF=0, HG_SAMPLE=1, ONB=2, DISK=3, COSINE_HEMI=4, REFLECT=5, BOUNDARY=6, SPIN=7, WALK_MATH=8, WALK_MATH_RAW=9)
+_FN_SHAPE = {0: (2, 1), 1: (2, 1), 2: (3, 6), 3: (2, 2), 4: (8, 4), 5: (6, 3), 6: (8, 5), 7: (5, 3), 8: (1, 5), 9: (1, 3)}
 
 # every symbol include/lt.h declares (tests check the library exports them all)
 SYMBOLS = [

@@ -1697,8 +1697,8 @@ int lt_intersect_bounds(lt_ctx* c, const double* origins, const double* dirs, co
 int lt_eval(lt_ctx* c, int fn, const double* in, size_t n, double* out)
 {
     CHECK_CTX(c);
-    static const int k_in[9] = {2, 2, 3, 2, 8, 6, 8, 5, 1}, k_out[9] = {1, 1, 6, 2, 4, 3, 5, 3, 5};
-    if (fn < 0 || fn > 8) return c->fail(LT_E_INVALID, "lt_eval: unknown function %d", fn);
+    static const int k_in[10] = {2, 2, 3, 2, 8, 6, 8, 5, 1, 1}, k_out[10] = {1, 1, 6, 2, 4, 3, 5, 3, 5, 3};
+    if (fn < 0 || fn > 9) return c->fail(LT_E_INVALID, "lt_eval: unknown function %d", fn);
     if (n == 0) return LT_OK;
     if (!in || !out) return c->fail(LT_E_INVALID, "lt_eval: null argument");
     BIND(c);

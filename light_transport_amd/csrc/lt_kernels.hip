@@ -278,6 +278,48 @@ LT_DEV void sincos_small_f64(double x, double* sn, double* cs)
     *cs = ((q + 1) & 2) ? -c1 : c1;
 }
 
+// The same two functions from the RAW 32-bit draw k (the uniform is (k + 1) 2^-32): exponent, table cell and remainder come out
+// of integer shifts instead of frexp / ldexp / rint in f64 -- ~5 f64 operations less each, and no conversion of the uniform.
+LT_DEV double neg_log_raw(unsigned k, const double* T)
+{
+    const unsigned n = k + 1u;                           // 0 stands for 2^32: the uniform is 1, -ln is 0
+    const int lz = __clz((int)n);
+    const unsigned nm = n << (lz & 31);                  // mantissa with bit 31 set: m = nm / 2^31 in [1, 2)
+    const unsigned hi = nm >= 0xC0000000u ? 1u : 0u;     // m >= 1.5: halve it -> [0.75, 1.5)
+    const unsigned sh = 24u + hi;                        // t = 128 m' = nm / 2^sh
+    const unsigned j = ((nm >> (sh - 1u)) + 1u) >> 1;    // rint(t): the cell's centre, 96 .. 192
+    const int dint = (int)(nm - (j << sh));              // (t - j) 2^sh, exact (modular arithmetic covers j 2^sh = 2^32)
+    const double d = __builtin_ldexp((double)dint, -(int)sh);
+    const double2 Tj = *reinterpret_cast<const double2*>(T + 2 * ((int)j - 96));
+    const double r = d * Tj.x;
+    double p = 1.0 / 7.0;
+    p = fma_k(p, r, -1.0 / 6.0); p = fma_k(p, r, 1.0 / 5.0); p = fma_k(p, r, -0.25); p = fma_k(p, r, 1.0 / 3.0);
+    p = __builtin_fma(p, r, -0.5);
+    const double lnm = Tj.y + __builtin_fma(r * r, p, r);
+    const double de = (double)((int)hi - 1 - lz);        // x = m' 2^e
+    const double v = -fma_mk(de, 6.93147180369123816490e-01, fma_mk(de, 1.90821492927058770002e-10, lnm));
+    return n == 0u ? 0.0 : v;
+}
+LT_DEV void sincos_turn_raw(unsigned k, const double* T, double* sn, double* cs)
+{
+    const unsigned n = k + 1u;                           // (n = 0 stands for a full turn: cell 0, remainder 0 -- nothing to special-case)
+    const unsigned iq = ((n >> 25) + 1u) >> 1;           // rint(64 xi)
+    const int drem = (int)(n - (iq << 26));              // (64 xi - iq) 2^26, exact
+    const double a = mul_k((double)drem, 1.4629180792671596e-09);      // 2 pi / 2^32; |a| <= pi / 64
+    const double z = a * a;
+    double ps = -1.9841269841269841270e-04;
+    ps = fma_k(ps, z, 8.3333333333333333333e-03);
+    ps = fma_k(ps, z, -1.6666666666666666667e-01);
+    const double sd = __builtin_fma(a * z, ps, a);
+    double pc = 2.4801587301587301587e-05;
+    pc = fma_k(pc, z, -1.3888888888888888889e-03);
+    pc = fma_k(pc, z, 4.1666666666666666667e-02);
+    pc = __builtin_fma(pc, z, -0.5);
+    const double cd = __builtin_fma(pc, z, 1.0);
+    const double2 Ti = *reinterpret_cast<const double2*>(T + 2 * (kLnTabEntries + (int)(iq & (unsigned)(kScTabEntries - 1))));
+    *sn = __builtin_fma(Ti.x, cd, Ti.y * sd);
+    *cs = __builtin_fma(Ti.y, cd, -(Ti.x * sd));
+}
 template <typename R> struct Mx;
 template <> struct Mx<double> {
     static LT_DEV double log(double x) { return ::log(x); }
@@ -549,6 +591,8 @@ template <typename R, bool TABLE> struct HeldU {
     static LT_DEV R draw(rocrand_state_xorwow* st) { return Mx<R>::uniform32(st); }
     static LT_DEV R as_real(R v) { return v; }
     static LT_DEV R from_real(R v) { return v; }
+    static LT_DEV R neg_log(R v, const double* T) { return Mx<R>::neg_log(v, T); }
+    static LT_DEV void sincos_turn(R v, const double* T, R* s, R* c) { Mx<R>::sincos_turn(v, T, s, c); }
 };
 template <> struct HeldU<double, false> {
     typedef unsigned type;
@@ -556,6 +600,8 @@ template <> struct HeldU<double, false> {
     static LT_DEV unsigned draw(rocrand_state_xorwow* st) { return rocrand(st); }
     static LT_DEV double as_real(unsigned v) { return (double)v; }       // (exact both ways: the march kernel parks it in an LDS array of R)
     static LT_DEV unsigned from_real(double v) { return (unsigned)v; }
+    static LT_DEV double neg_log(unsigned v, const double* T) { return neg_log_raw(v, T); }
+    static LT_DEV void sincos_turn(unsigned v, const double* T, double* s, double* c) { sincos_turn_raw(v, T, s, c); }
 };
 
 // c0 of the cell that holds (px, py, pz): -1 outside the grid (always query)
@@ -999,10 +1045,10 @@ template <typename R> LT_DEV R boundary_planar(R uz, R n1, R n2, R Nr, R* cos_t_
 }
 
 // Spin (App. C.6): MCML direction update, |uz| > 0.99999 special case.
-template <typename R> LT_DEV void spin(R* u, R ct, R xi_phi, const double* T)      // T: kWalkMathTab or its LDS copy (f64 walks)
+template <typename R, bool TABLE> LT_DEV void spin(R* u, R ct, typename HeldU<R, TABLE>::type xi_phi, const double* T)      // xi_phi: the azimuth's uniform as the walk carries it (f64 XORWOW: the raw draw); T: kWalkMathTab or its LDS copy
 {
     const R st2 = Mx<R>::max0((R)1 - ct * ct);          // sin^2(theta); a rounding-negative value is 0
-    R sp, cp; Mx<R>::sincos_turn(xi_phi, T, &sp, &cp);
+    R sp, cp; HeldU<R, TABLE>::sincos_turn(xi_phi, T, &sp, &cp);
     R ux = u[0], uy = u[1], uz = u[2];
     if (Mx<R>::abs(uz) > (R)0.99999) {
         const R st = Mx<R>::sqrt_unit(st2);
@@ -1506,7 +1552,7 @@ __global__ void k_eval(int fn, const double* in, size_t n, double* out)
     } break;
     case LT_FN_SPIN: {
         double u[3] = {in[5 * i], in[5 * i + 1], in[5 * i + 2]};
-        spin(u, in[5 * i + 3], in[5 * i + 4], kWalkMathTab);
+        spin<double, true>(u, in[5 * i + 3], in[5 * i + 4], kWalkMathTab);
         for (int k = 0; k < 3; k++) out[3 * i + k] = u[k];
     } break;
     case LT_FN_WALK_MATH: {   // the walk's lean f64 primitives: -ln x, sin/cos(2 pi x), sqrt x, 1 / (1 + x)
@@ -1515,6 +1561,11 @@ __global__ void k_eval(int fn, const double* in, size_t n, double* out)
         sincos_turn_tab(x, kWalkMathTab, &out[5 * i + 1], &out[5 * i + 2]);
         out[5 * i + 3] = sqrt01(x);
         out[5 * i + 4] = fast_div(1.0, 1.0 + x);
+    } break;
+    case LT_FN_WALK_MATH_RAW: {   // ... and the forms the f64 XORWOW walk applies to the raw draw
+        const unsigned k = (unsigned)in[i];
+        out[3 * i] = neg_log_raw(k, kWalkMathTab);
+        sincos_turn_raw(k, kWalkMathTab, &out[3 * i + 1], &out[3 * i + 2]);
     } break;
     }
 }

@@ -158,6 +158,27 @@ def test_walk_math_primitives(ctx):
     assert abs(z[0, 2] - 1.0) < 3e-16 and z[0, 3] == 1.0
 
 
+def test_walk_math_from_raw_draws(ctx):
+    """The forms the f64 XORWOW walk applies to a RAW 32-bit draw k (u = (k + 1) 2^-32: exponent, table cell and remainder by
+    integer shifts) against the host libm and against the double-argument forms of the same tables."""
+    rs = np.random.RandomState(3)
+    k = np.concatenate([rs.randint(0, 2 ** 32, size=200000, dtype=np.uint64), 2 ** np.arange(0, 32, dtype=np.uint64) - 1,
+                        2 ** np.arange(1, 33, dtype=np.uint64) - 2, [0, 1, 2, 2 ** 32 - 1, 2 ** 31, 2 ** 31 - 1, 3 * 2 ** 30 - 1, 3 * 2 ** 30,
+                                                                      2 ** 26 - 1, 2 ** 25 - 1, 2 ** 25]]).astype(np.float64)
+    u = (k + 1.0) * 2.0 ** -32                          # exact
+    out = ctx.eval("WALK_MATH_RAW", k[:, None])
+    ref = -np.log(u)
+    assert np.all(np.abs(out[:, 0] - ref) <= 4e-16 * np.maximum(np.abs(ref), 2.0 ** -53)), "neg_log_raw"
+    assert out[u == 1.0, 0].max() == 0.0
+    two_pi = 2 * np.longdouble("3.14159265358979323846264338327950288")
+    ang = two_pi * u.astype(np.longdouble)
+    np.testing.assert_allclose(out[:, 1], np.sin(ang).astype(np.float64), rtol=0, atol=3e-16)
+    np.testing.assert_allclose(out[:, 2], np.cos(ang).astype(np.float64), rtol=0, atol=3e-16)
+    dbl = ctx.eval("WALK_MATH", u[:, None])
+    np.testing.assert_allclose(out[:, 0], dbl[:, 0], rtol=3e-16, atol=1e-300)
+    np.testing.assert_allclose(out[:, 1:3], dbl[:, 1:3], rtol=0, atol=2e-16)
+
+
 # ---------------------------------------------------------------- the walk vs the oracle
 def run_gpu(ctx, prob, n, dtype="f64", **kw):
     prob.apply(ctx, dtype)
